@@ -1,0 +1,134 @@
+/*
+ * C-ABI HIP layer: the MI355X replacement for the reference's OpenCL
+ * plumbing.  Plain pointers and sizes only; every entry point returns 0 on
+ * success and a non-zero code on failure (text via rt_hip_last_error()).
+ * The rt_render_pipe_* API (rt_funcs_render_pipe.h) is built on top of it;
+ * callers that keep a scene resident (benchmarks, multi-GPU drivers) may use
+ * it directly.
+ *
+ * What each group replaces in the reference (rt_funcs_render_pipe.c):
+ *   rt_hip_create / _destroy          rt_init_opencl            :398-495
+ *   rt_hip_upload_* / _set_camera     rt_init_buffers, rt_add_block and the
+ *                                     clEnqueueWrite/Map calls  :127-396
+ *   rt_hip_upload_tree                the memn/memi buffers     :1171-1207
+ *   rt_hip_set_image / _set_tile      rt_render_pipe_calc_wg_size + the
+ *                                     NDRange set-up            :33-94,:534-536
+ *   rt_hip_render / _read_frame       rt_opencl_render          :497-573
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_hip_ctx rt_hip_ctx;
+
+/* ---- HBM layouts -------------------------------------------------------- */
+
+/*
+ * 8-byte kd node, pre-order, left child = own index + 1.
+ *   inner: a = bits of the fp32 split position, b = (rightIndex << 2) | axis
+ *   leaf : a = index of the first triangle record, b = (count << 2) | 3
+ */
+typedef struct _rt_hip_kdnode { uint32_t a, b; } rt_hip_kdnode;
+
+/* 48-byte leaf triangle record: one per (leaf, triangle) reference, stored in
+ * leaf order, so a leaf scan is one contiguous read with no indirection.
+ * e1 = v1 - v0 and e2 = v2 - v0 are the fp32 differences the intersection
+ * test would otherwise compute itself. */
+typedef struct _rt_hip_trirec
+{
+	float    v0[3], e1[3], e2[3];
+	uint32_t tri;     /* index into the triangle / shading arrays */
+	uint32_t mat;     /* material slot */
+	uint32_t _pad;
+} rt_hip_trirec;
+
+/* 48-byte per-triangle shading record (vertex normals + material slot) */
+typedef struct _rt_hip_trishade
+{
+	float    n0[3], n1[3], n2[3];
+	uint32_t mat;
+	uint32_t _pad[2];
+} rt_hip_trishade;
+
+typedef struct _rt_hip_stats
+{
+	uint64_t raysClosest;   /* closest-hit queries                         */
+	uint64_t raysShadow;    /* shadow queries                              */
+	uint64_t hits;          /* shaded hits                                 */
+	uint64_t nodeVisits;    /* kd nodes touched   (RT_HIP_STATS only)      */
+	uint64_t triTests;      /* triangle tests     (RT_HIP_STATS only)      */
+	uint64_t spillPushes;   /* stack pushes that went past LDS (STATS)     */
+	uint64_t maxStack;      /* deepest traversal stack seen (STATS)        */
+	uint64_t _reserved;
+} rt_hip_stats;
+
+/* rt_hip_render flags */
+#define RT_HIP_STATS    1u   /* run the counting variant of the kernels    */
+#define RT_HIP_HITIDS   2u   /* record the primary ray's hit id per pixel  */
+#define RT_HIP_TIMING   4u   /* bracket every launch with HIP events       */
+
+/* hit ids: triangle index, -1 = miss, -2-i = sphere i */
+#define RT_HIP_HIT_MISS (-1)
+
+/* rt_hip_set_param keys */
+#define RT_PARAM_STACK_SIZE        1   /* rays per pixel, 1..RT_STACK_SIZE_MAX, default 6 */
+#define RT_PARAM_MAX_DEPTH         2   /* kd depth cap, default 10 (render pipe only)     */
+#define RT_PARAM_MAX_PRIMS_IN_NODE 3   /* kd leaf size, default 7 (render pipe only)      */
+#define RT_PARAM_BUILD_THREADS     4   /* host builder threads, 0 = automatic             */
+#define RT_PARAM_TREE_CACHE        5   /* 1 = reuse the tree while geometry is unchanged  */
+
+#define RT_HIP_MAX_TREE_DEPTH 64       /* deepest tree the traversal stack admits */
+
+int  rt_hip_device_count( void );
+const char *rt_hip_last_error( void );
+
+rt_hip_ctx *rt_hip_create( int device );              /* NULL on failure */
+void rt_hip_destroy( rt_hip_ctx *c );
+/* run on a caller-owned hipStream_t (e.g. the framework's current stream);
+ * NULL selects the context's own stream */
+int  rt_hip_set_stream( rt_hip_ctx *c, void *hipStream );
+
+int  rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes,
+	const rt_hip_trirec *recs, uint64_t nRecs, const rt_hip_trishade *shade,
+	uint64_t nTris, const rt_box *bbox, int depth );
+int  rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n );
+int  rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n );
+int  rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n );
+int  rt_hip_set_camera( rt_hip_ctx *c, const rt_camera *cam );
+
+/* full image size; allocates the per-pixel work buffers */
+int  rt_hip_set_image( rt_hip_ctx *c, int w, int h );
+/*
+ * Multi-GPU split (no reference counterpart): the image is cut into bands of
+ * bandH rows; this context renders bands part, part+nParts, ... and stores
+ * them compactly (local row = (band/nParts)*bandH + row%bandH).
+ * nParts = 1 renders the whole frame.
+ */
+int  rt_hip_set_tile( rt_hip_ctx *c, int bandH, int nParts, int part );
+int  rt_hip_local_rows( rt_hip_ctx *c );              /* rows this context renders */
+int  rt_hip_set_param( rt_hip_ctx *c, int key, int value );
+
+/*
+ * Enqueue one frame on the stream: ray generation, closest-hit / shading
+ * passes for every ray slot, colour fold, 8-bit store.  d_out is a DEVICE
+ * buffer of w * rt_hip_local_rows() rt_argb, or NULL to use the context's
+ * own frame buffer.  Asynchronous.
+ */
+int  rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags );
+int  rt_hip_sync( rt_hip_ctx *c );
+int  rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host );        /* internal frame buffer -> host, synchronous */
+int  rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host );      /* after RT_HIP_HITIDS */
+int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
+/* after RT_HIP_TIMING: ms[0] = closest-hit passes, ms[1] = shading passes,
+ * ms[2] = fold + store, ms[3] = whole frame; launches[i] = launch counts */
+int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[4], int launches[4] );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+/*
+ * Host kd-tree builder that emits the HBM layout of rt_hip.h directly.
+ *
+ * Same algorithm and fp32 arithmetic as the reference's builder
+ * (rt_funcs_render_pipe.c:591-1209: scene box padded by 1, longest-axis
+ * split, 32 SAH candidate planes, lowest-index argmin, stable partition by
+ * triangle extent, leaf at <= maxPrims triangles or at maxDepth), therefore
+ * the same tree, but
+ *   - per-triangle extents are computed once instead of 32 times per level,
+ *   - candidate counts come from one histogram pass (two binary searches
+ *     per triangle) instead of 32 passes,
+ *   - sub-trees are built by a pool of worker threads instead of eight
+ *     threads created and joined per node,
+ *   - maxDepth / maxPrims are run-time parameters (reference: 10 and 7).
+ */
+#ifndef RT_KDTREE_H
+#define RT_KDTREE_H
+
+#include "rt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct _rt_kdtree_flat
+{
+	rt_hip_kdnode   *nodes;   uint64_t nNodes;
+	rt_hip_trirec   *recs;    uint64_t nRecs;
+	rt_hip_trishade *shade;   uint64_t nTris;
+	rt_box bbox;
+	int depth;                /* deepest leaf, root = 0 */
+} rt_kdtree_flat;
+
+/* Returns 0 on success.  threads <= 0 picks the number of online CPUs
+ * (capped at 16).  Triangle vertex indices must be global and < vertexCount. */
+int  rt_kdtree_build_flat( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, int maxDepth, int maxPrims, int threads, rt_kdtree_flat *out );
+void rt_kdtree_flat_release( rt_kdtree_flat *t );
+
+/* Expands the HBM layout back into the reference's flat interchange format
+ * (48-byte nodes + uint64 index list); arrays are malloc'ed. */
+int  rt_kdtree_flat_expand( const rt_kdtree_flat *t, rt_cl_kdtree_node **nodes, uint64_t *nodesCount,
+	rt_ulong **primsIdx, uint64_t *primsIdxCount );
+
+/* Converts a tree given in the interchange format into the HBM layout. */
+int  rt_kdtree_flatten( const rt_cl_kdtree_node *nodes, uint64_t nodesCount, const rt_ulong *primsIdx,
+	uint64_t primsIdxCount, const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, const rt_box *bbox, rt_kdtree_flat *out );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

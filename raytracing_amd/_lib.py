@@ -1,0 +1,76 @@
+"""Loader of the product's C-ABI library (librt_amd.so).
+
+There is no fallback: if the library is missing or a device call fails the
+caller gets an exception, never a CPU result.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "librt_amd.so")
+_lib = None
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("raysClosest", "raysShadow", "hits", "nodeVisits", "triTests",
+                 "spillPushes", "maxStack", "_reserved")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if not n.startswith("_")}
+
+
+class FlatTree(C.Structure):      # rt_kdtree_flat
+    _fields_ = [("nodes", C.c_void_p), ("nNodes", C.c_uint64),
+                ("recs", C.c_void_p), ("nRecs", C.c_uint64),
+                ("shade", C.c_void_p), ("nTris", C.c_uint64),
+                ("bbox", C.c_float * 8), ("depth", C.c_int)]
+
+
+class RenderPipeStruct(C.Structure):   # rt_render_pipe
+    _fields_ = [("impl", C.c_void_p)] + [(n, C.c_uint64) for n in
+                ("primBlocks", "primDecsBlocks", "lightBlocks", "lightDecsBlocks",
+                 "triangleBlocks", "vertexBlocks", "materialBlocks")] + [
+                ("primsEnd", C.c_size_t), ("primsCount", C.c_uint64),
+                ("lightsEnd", C.c_size_t), ("lightsCount", C.c_uint64),
+                ("trianglesCount", C.c_uint64), ("vertexCount", C.c_uint64),
+                ("screenData", C.c_void_p), ("w", C.c_int), ("h", C.c_int)]
+
+
+def build():
+    """Compile librt_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.run(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RtError(f"{SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `make -C raytracing_amd/csrc`) first")
+        L = C.CDLL(SO)
+        L.rt_hip_last_error.restype = C.c_char_p
+        L.rt_hip_create.restype = C.c_void_p
+        L.rt_hip_create.argtypes = [C.c_int]
+        L.rt_hip_destroy.argtypes = [C.c_void_p]
+        L.rt_render_pipe_hip.restype = C.c_void_p
+        L.rt_render_pipe_draw.restype = C.c_void_p
+        for name in ("rt_hip_set_stream", "rt_hip_upload_tree", "rt_hip_upload_materials",
+                     "rt_hip_upload_spheres", "rt_hip_upload_lights", "rt_hip_set_camera",
+                     "rt_hip_set_image", "rt_hip_set_tile", "rt_hip_local_rows", "rt_hip_set_param",
+                     "rt_hip_render", "rt_hip_sync", "rt_hip_read_frame", "rt_hip_read_hit_ids",
+                     "rt_hip_get_stats", "rt_hip_kernel_times", "rt_kdtree_build_flat",
+                     "rt_kdtree_flat_expand", "rt_kdtree_flatten", "rt_hip_device_count"):
+            getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RtError(f"{what}: {lib().rt_hip_last_error().decode()} (code {rc})")

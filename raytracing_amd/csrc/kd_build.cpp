@@ -1,0 +1,666 @@
+// Host kd-tree builder (see include/rt_kdtree.h for what it keeps from the
+// reference's builder, rt_funcs_render_pipe.c:591-1209, and what it changes).
+//
+// All fp32 expressions are written in the reference's operand order and this
+// file is compiled with -ffp-contract=off: the split positions, counts and
+// child boxes, and therefore the tree, are the reference's bit for bit.
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include <unistd.h>
+
+#include "rt_funcs_render_pipe.h"
+#include "rt_kdtree.h"
+
+namespace {
+
+inline float box_c( const rt_box &b, int ax ) { return ax == 0 ? b.center.x : ax == 1 ? b.center.y : b.center.z; }
+inline float box_e( const rt_box &b, int ax ) { return ax == 0 ? b.extents.x : ax == 1 ? b.extents.y : b.extents.z; }
+inline void box_set( rt_box &b, int ax, float c, float e )
+{
+	if ( ax == 0 ) { b.center.x = c; b.extents.x = e; }
+	else if ( ax == 1 ) { b.center.y = c; b.extents.y = e; }
+	else { b.center.z = c; b.extents.z = e; }
+}
+
+// extent of one triangle on one axis: the compare chain of the reference
+// (rt_funcs_render_pipe.c:620-633)
+inline void tri_extent( float a, float b, float c, float &mn, float &mx )
+{
+	mx = a;
+	if ( mx < b ) mx = b;
+	if ( mx < c ) mx = c;
+	mn = a;
+	if ( mn > b ) mn = b;
+	if ( mn > c ) mn = c;
+}
+
+// longest half extent, ties X > Y > Z (:945-957)
+inline int split_axis( const rt_box &b )
+{
+	float range = b.extents.x;
+	int ax = RT_AXIS_X;
+	if ( range < b.extents.y ) { range = b.extents.y; ax = RT_AXIS_Y; }
+	if ( range < b.extents.z ) { range = b.extents.z; ax = RT_AXIS_Z; }
+	return ax;
+}
+
+// child boxes: slab split at sep (:1034-1073)
+inline void child_boxes( const rt_box &b, int ax, float sep, rt_box &l, rt_box &r )
+{
+	l = r = b;
+	box_set( l, ax, 0.5f * ( box_c( b, ax ) - box_e( b, ax ) + sep ), 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) ) );
+	box_set( r, ax, 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep ), 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep ) );
+}
+
+// The SAH sweep of :591-857 for triangles given by their extents on the split
+// axis.  get(j, mn, mx) yields the extent of the node's j-th triangle.
+// Candidate i is sep_i = min + i * delta; NL_i = #(mn < sep_i), NR_i = #(mx > sep_i);
+// the winner is the lowest i with the strictly smallest cost.
+template <class Get>
+void sah_sweep( uint64_t n, int ax, const rt_box &box, Get get, uint64_t &cntL, uint64_t &cntR, float &outSep )
+{
+	const float c = box_c( box, ax ), e = box_e( box, ax );
+	const float mn = c - e, mx = c + e;
+	const float delta = ( mx - mn ) / (float) SAH_PARTS;
+	float eA, eB;
+	if ( ax == 0 ) { eA = box.extents.y; eB = box.extents.z; }
+	else if ( ax == 1 ) { eA = box.extents.x; eB = box.extents.z; }
+	else { eA = box.extents.x; eB = box.extents.y; }
+	const float area = eA * eB;
+
+	float seps[SAH_PARTS];
+	bool sorted = true;
+	for ( int i = 0; i < SAH_PARTS; ++i )
+	{
+		seps[i] = mn + i * delta;
+		if ( i && !( seps[i - 1] <= seps[i] ) ) sorted = false;
+	}
+
+	uint64_t L[SAH_PARTS], R[SAH_PARTS];
+	if ( sorted )
+	{
+		// one pass: histL[k] = #triangles whose first candidate above mn is k,
+		// histR[k] = #triangles with exactly k candidates below mx
+		uint64_t histL[SAH_PARTS + 1] = { 0 }, histR[SAH_PARTS + 1] = { 0 };
+		for ( uint64_t j = 0; j < n; ++j )
+		{
+			float a, b;
+			get( j, a, b );
+			int lo = 0, hi = 0;
+			for ( int step = SAH_PARTS / 2; step; step >>= 1 )      // seps has 32 entries: 5 steps + 1
+			{
+				if ( !( a < seps[lo + step - 1] ) ) lo += step;
+				if ( b > seps[hi + step - 1] ) hi += step;
+			}
+			if ( lo < SAH_PARTS && !( a < seps[lo] ) ) ++lo;
+			if ( hi < SAH_PARTS && b > seps[hi] ) ++hi;
+			++histL[lo];
+			++histR[hi];
+		}
+		uint64_t acc = 0;
+		for ( int i = 0; i < SAH_PARTS; ++i ) { acc += histL[i]; L[i] = acc; }
+		acc = 0;
+		for ( int i = SAH_PARTS - 1; i >= 0; --i ) { acc += histR[i + 1]; R[i] = acc; }
+	}
+	else
+	{
+		// degenerate box (NaN / inverted): literal 32-pass count
+		for ( int i = 0; i < SAH_PARTS; ++i )
+		{
+			uint64_t l = 0, r = 0;
+			for ( uint64_t j = 0; j < n; ++j )
+			{
+				float a, b;
+				get( j, a, b );
+				if ( a < seps[i] ) ++l;
+				if ( b > seps[i] ) ++r;
+			}
+			L[i] = l;
+			R[i] = r;
+		}
+	}
+
+	float best = 0.0f;
+	for ( int i = 0; i < SAH_PARTS; ++i )
+	{
+		const float sep = seps[i];
+		float sah = ( area + ( sep - c + e ) * ( eA + eB ) ) * L[i] + ( area + ( c + e - sep ) * ( eA + eB ) ) * R[i];
+		if ( i == 0 || sah < best )
+		{
+			best = sah;
+			outSep = sep;
+			cntL = L[i];
+			cntR = R[i];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// parallel builder producing the HBM layout
+// ---------------------------------------------------------------------------
+
+struct BNode
+{
+	BNode *l = nullptr, *r = nullptr;
+	std::vector<uint32_t> prims;     // leaves only
+	float sep = 0.0f;
+	int axis = 0;
+	bool leaf = false;
+	uint64_t nodes = 1, refs = 0;    // sub-tree totals
+	int depth = 0;                   // deepest leaf below, relative to this node
+};
+
+struct Task { BNode *node; std::vector<uint32_t> prims; rt_box box; int depth; };
+
+struct Pool
+{
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Task> q;
+	size_t pending = 0;
+	bool failed = false;
+};
+
+struct Builder
+{
+	const float *tmin[3], *tmax[3];
+	int maxDepth, maxPrims;
+	Pool pool;
+	size_t spawnThreshold = 2048;
+
+	void split( BNode *node, std::vector<uint32_t> &prims, const rt_box &box, int depth, bool mayspawn )
+	{
+		const uint64_t n = prims.size();
+		if ( n <= (uint64_t) maxPrims || depth == maxDepth )
+		{
+			node->leaf = true;
+			node->prims.swap( prims );
+			return;
+		}
+		const int ax = split_axis( box );
+		const float *mnA = tmin[ax], *mxA = tmax[ax];
+		uint64_t cl = 0, cr = 0;
+		float sep = 0.0f;
+		const uint32_t *pp = prims.data();
+		sah_sweep( n, ax, box, [&]( uint64_t j, float &a, float &b ) { a = mnA[pp[j]]; b = mxA[pp[j]]; }, cl, cr, sep );
+
+		std::vector<uint32_t> pl, pr;
+		pl.reserve( cl );
+		pr.reserve( cr );
+		for ( uint64_t i = 0; i < n; ++i )        // stable partition (:971-1029)
+		{
+			const uint32_t p = pp[i];
+			if ( mnA[p] < sep ) pl.push_back( p );
+			if ( mxA[p] > sep ) pr.push_back( p );
+		}
+		std::vector<uint32_t>().swap( prims );
+
+		rt_box bl, br;
+		child_boxes( box, ax, sep, bl, br );
+		node->sep = sep;
+		node->axis = ax;
+		node->l = new BNode();
+		node->r = new BNode();
+
+		if ( mayspawn && pr.size() >= spawnThreshold && pl.size() >= spawnThreshold )
+		{
+			// hand the right sub-tree to another worker, keep the left one
+			{
+				std::lock_guard<std::mutex> g( pool.mu );
+				pool.q.push_back( Task{ node->r, std::move( pr ), br, depth + 1 } );
+				++pool.pending;
+			}
+			pool.cv.notify_one();
+			split( node->l, pl, bl, depth + 1, true );
+		}
+		else
+		{
+			split( node->l, pl, bl, depth + 1, mayspawn );
+			split( node->r, pr, br, depth + 1, mayspawn );
+		}
+	}
+
+	void worker()
+	{
+		for ( ;; )
+		{
+			Task t;
+			{
+				std::unique_lock<std::mutex> g( pool.mu );
+				pool.cv.wait( g, [&] { return !pool.q.empty() || pool.pending == 0; } );
+				if ( pool.q.empty() )
+					return;
+				t = std::move( pool.q.front() );
+				pool.q.pop_front();
+			}
+			split( t.node, t.prims, t.box, t.depth, true );
+			{
+				std::lock_guard<std::mutex> g( pool.mu );
+				--pool.pending;
+				if ( pool.pending == 0 )
+					pool.cv.notify_all();
+			}
+		}
+	}
+};
+
+void totals( BNode *n )
+{
+	if ( n->leaf )
+	{
+		n->nodes = 1;
+		n->refs = n->prims.size();
+		n->depth = 0;
+		return;
+	}
+	totals( n->l );
+	totals( n->r );
+	n->nodes = 1 + n->l->nodes + n->r->nodes;
+	n->refs = n->l->refs + n->r->refs;
+	n->depth = 1 + std::max( n->l->depth, n->r->depth );
+}
+
+// pre-order packing, left child right behind its parent (:860-912)
+void pack( BNode *n, uint64_t pos, uint64_t ref, rt_hip_kdnode *nodes, uint32_t *order )
+{
+	if ( n->leaf )
+	{
+		nodes[pos].a = (uint32_t) ref;
+		nodes[pos].b = ( (uint32_t) n->prims.size() << 2 ) | 3u;
+		if ( !n->prims.empty() )
+			memcpy( order + ref, n->prims.data(), n->prims.size() * sizeof( uint32_t ) );
+		delete n;
+		return;
+	}
+	uint64_t right = pos + 1 + n->l->nodes;
+	uint64_t rref = ref + n->l->refs;
+	memcpy( &nodes[pos].a, &n->sep, 4 );
+	nodes[pos].b = ( (uint32_t) right << 2 ) | (uint32_t) n->axis;
+	BNode *l = n->l, *r = n->r;
+	delete n;
+	pack( l, pos + 1, ref, nodes, order );
+	pack( r, right, rref, nodes, order );
+}
+
+void scene_box( const rt_vertex *verts, uint64_t n, rt_box &bbox )
+{
+	// :1114-1137: min / max over all vertices, padded by 1, centre + half size
+	float mnx = 0, mny = 0, mnz = 0, mxx = 0, mxy = 0, mxz = 0;
+	for ( uint64_t i = 0; i < n; ++i )
+	{
+		const rt_vector3 &p = verts[i].pos;
+		mnx = ( mnx > p.x || i == 0 ) ? p.x : mnx;
+		mny = ( mny > p.y || i == 0 ) ? p.y : mny;
+		mnz = ( mnz > p.z || i == 0 ) ? p.z : mnz;
+		mxx = ( mxx < p.x || i == 0 ) ? p.x : mxx;
+		mxy = ( mxy < p.y || i == 0 ) ? p.y : mxy;
+		mxz = ( mxz < p.z || i == 0 ) ? p.z : mxz;
+	}
+	mnx -= 1.0f; mny -= 1.0f; mnz -= 1.0f;
+	mxx += 1.0f; mxy += 1.0f; mxz += 1.0f;
+	memset( &bbox, 0, sizeof( bbox ) );
+	bbox.center.x = ( mnx + mxx ) * 0.5f;
+	bbox.center.y = ( mny + mxy ) * 0.5f;
+	bbox.center.z = ( mnz + mxz ) * 0.5f;
+	bbox.extents.x = ( mxx - mnx ) * 0.5f;
+	bbox.extents.y = ( mxy - mny ) * 0.5f;
+	bbox.extents.z = ( mxz - mnz ) * 0.5f;
+}
+
+void fill_records( const rt_vertex *verts, const rt_triangle *tris, uint64_t nTris, const uint32_t *order,
+	uint64_t nRecs, rt_hip_trirec *recs, rt_hip_trishade *shade, int threads )
+{
+	auto recRange = [&]( uint64_t b, uint64_t e ) {
+		for ( uint64_t i = b; i < e; ++i )
+		{
+			const rt_triangle &t = tris[order[i]];
+			const rt_vector3 &p0 = verts[t.pV0].pos, &p1 = verts[t.pV1].pos, &p2 = verts[t.pV2].pos;
+			rt_hip_trirec &r = recs[i];
+			r.v0[0] = p0.x; r.v0[1] = p0.y; r.v0[2] = p0.z;
+			r.e1[0] = p1.x - p0.x; r.e1[1] = p1.y - p0.y; r.e1[2] = p1.z - p0.z;
+			r.e2[0] = p2.x - p0.x; r.e2[1] = p2.y - p0.y; r.e2[2] = p2.z - p0.z;
+			r.tri = order[i];
+			r.mat = (uint32_t) t.mat;
+			r._pad = 0;
+		}
+	};
+	auto shadeRange = [&]( uint64_t b, uint64_t e ) {
+		for ( uint64_t i = b; i < e; ++i )
+		{
+			const rt_triangle &t = tris[i];
+			const rt_vector3 &n0 = verts[t.pV0].norm, &n1 = verts[t.pV1].norm, &n2 = verts[t.pV2].norm;
+			rt_hip_trishade &s = shade[i];
+			s.n0[0] = n0.x; s.n0[1] = n0.y; s.n0[2] = n0.z;
+			s.n1[0] = n1.x; s.n1[1] = n1.y; s.n1[2] = n1.z;
+			s.n2[0] = n2.x; s.n2[1] = n2.y; s.n2[2] = n2.z;
+			s.mat = (uint32_t) t.mat;
+			s._pad[0] = s._pad[1] = 0;
+		}
+	};
+	if ( threads <= 1 || nRecs + nTris < 65536 )
+	{
+		recRange( 0, nRecs );
+		shadeRange( 0, nTris );
+		return;
+	}
+	std::vector<std::thread> th;
+	for ( int k = 0; k < threads; ++k )
+		th.emplace_back( [&, k] {
+			recRange( nRecs * k / threads, nRecs * ( k + 1 ) / threads );
+			shadeRange( nTris * k / threads, nTris * ( k + 1 ) / threads );
+		} );
+	for ( auto &t : th ) t.join();
+}
+
+int pick_threads( int threads )
+{
+	if ( threads > 0 )
+		return std::min( threads, 64 );
+	long n = sysconf( _SC_NPROCESSORS_ONLN );
+	if ( const char *e = getenv( "OMP_NUM_THREADS" ) )
+	{
+		int v = atoi( e );
+		if ( v > 0 && v < n ) n = v;
+	}
+	if ( n < 1 ) n = 1;
+	return (int) std::min<long>( n, 16 );
+}
+
+} // namespace
+
+extern "C" int rt_kdtree_build_flat( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, int maxDepth, int maxPrims, int threads, rt_kdtree_flat *out )
+{
+	if ( !out || ( vertexCount && !verts ) || ( trianglesCount && !tris ) )
+		return 1;
+	if ( trianglesCount >= ( 1ull << 30 ) || maxDepth < 0 || maxDepth > RT_HIP_MAX_TREE_DEPTH || maxPrims < 1 )
+		return 2;
+	for ( uint64_t i = 0; i < trianglesCount; ++i )
+		if ( tris[i].pV0 >= vertexCount || tris[i].pV1 >= vertexCount || tris[i].pV2 >= vertexCount )
+			return 3;
+	memset( out, 0, sizeof( *out ) );
+	threads = pick_threads( threads );
+	scene_box( verts, vertexCount, out->bbox );
+
+	const uint64_t nT = trianglesCount;
+	std::vector<float> ext( 6 * ( nT ? nT : 1 ) );
+	{
+		auto range = [&]( uint64_t b, uint64_t e ) {
+			for ( uint64_t i = b; i < e; ++i )
+			{
+				const rt_vector3 &p0 = verts[tris[i].pV0].pos, &p1 = verts[tris[i].pV1].pos, &p2 = verts[tris[i].pV2].pos;
+				tri_extent( p0.x, p1.x, p2.x, ext[i], ext[3 * nT + i] );
+				tri_extent( p0.y, p1.y, p2.y, ext[nT + i], ext[4 * nT + i] );
+				tri_extent( p0.z, p1.z, p2.z, ext[2 * nT + i], ext[5 * nT + i] );
+			}
+		};
+		if ( threads > 1 && nT >= 65536 )
+		{
+			std::vector<std::thread> th;
+			for ( int k = 0; k < threads; ++k )
+				th.emplace_back( range, nT * k / threads, nT * ( k + 1 ) / threads );
+			for ( auto &t : th ) t.join();
+		}
+		else
+			range( 0, nT );
+	}
+
+	Builder b;
+	for ( int a = 0; a < 3; ++a )
+	{
+		b.tmin[a] = ext.data() + a * nT;
+		b.tmax[a] = ext.data() + ( 3 + a ) * nT;
+	}
+	b.maxDepth = maxDepth;
+	b.maxPrims = maxPrims;
+
+	BNode *root = new BNode();
+	{
+		std::vector<uint32_t> all( nT );
+		for ( uint64_t i = 0; i < nT; ++i ) all[i] = (uint32_t) i;
+		b.pool.q.push_back( Task{ root, std::move( all ), out->bbox, 0 } );
+		b.pool.pending = 1;
+	}
+	if ( threads > 1 && nT >= 4 * b.spawnThreshold )
+	{
+		std::vector<std::thread> th;
+		for ( int k = 0; k < threads; ++k )
+			th.emplace_back( [&] { b.worker(); } );
+		for ( auto &t : th ) t.join();
+	}
+	else
+		b.worker();
+
+	totals( root );
+	if ( root->nodes >= ( 1ull << 30 ) || root->refs >= ( 1ull << 30 ) )
+		return 4;          // 30-bit links of the 8-byte node
+	out->nNodes = root->nodes;
+	out->nRecs = root->refs;
+	out->nTris = nT;
+	out->depth = root->depth;
+	out->nodes = (rt_hip_kdnode *) malloc( sizeof( rt_hip_kdnode ) * out->nNodes );
+	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( out->nRecs ? out->nRecs : 1 ) );
+	out->shade = (rt_hip_trishade *) malloc( sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
+	std::vector<uint32_t> order( out->nRecs ? out->nRecs : 1 );
+	pack( root, 0, 0, out->nodes, order.data() );
+	fill_records( verts, tris, nT, order.data(), out->nRecs, out->recs, out->shade, threads );
+	return 0;
+}
+
+extern "C" void rt_kdtree_flat_release( rt_kdtree_flat *t )
+{
+	if ( !t )
+		return;
+	free( t->nodes );
+	free( t->recs );
+	free( t->shade );
+	memset( t, 0, sizeof( *t ) );
+}
+
+extern "C" int rt_kdtree_flat_expand( const rt_kdtree_flat *t, rt_cl_kdtree_node **nodes, uint64_t *nodesCount,
+	rt_ulong **primsIdx, uint64_t *primsIdxCount )
+{
+	if ( !t || !nodes || !nodesCount || !primsIdx || !primsIdxCount )
+		return 1;
+	rt_cl_kdtree_node *n = (rt_cl_kdtree_node *) calloc( t->nNodes ? t->nNodes : 1, sizeof( rt_cl_kdtree_node ) );
+	rt_ulong *idx = (rt_ulong *) calloc( t->nRecs ? t->nRecs : 1, sizeof( rt_ulong ) );
+	for ( uint64_t i = 0; i < t->nNodes; ++i )
+	{
+		const rt_hip_kdnode &s = t->nodes[i];
+		if ( ( s.b & 3u ) == 3u )
+		{
+			n[i].isLast = 1;
+			n[i].primsCount = s.b >> 2;
+			n[i].prims = s.a;
+		}
+		else
+		{
+			memcpy( &n[i].sep, &s.a, 4 );
+			n[i].axis = (RT_AXIS) ( s.b & 3u );
+			n[i].leftNode = i + 1;
+			n[i].rightNode = s.b >> 2;
+		}
+	}
+	for ( uint64_t i = 0; i < t->nRecs; ++i )
+		idx[i] = t->recs[i].tri;
+	*nodes = n;
+	*nodesCount = t->nNodes;
+	*primsIdx = idx;
+	*primsIdxCount = t->nRecs;
+	return 0;
+}
+
+extern "C" int rt_kdtree_flatten( const rt_cl_kdtree_node *nodes, uint64_t nodesCount, const rt_ulong *primsIdx,
+	uint64_t primsIdxCount, const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, const rt_box *bbox, rt_kdtree_flat *out )
+{
+	if ( !nodes || !nodesCount || !out || !bbox || ( primsIdxCount && !primsIdx ) )
+		return 1;
+	if ( nodesCount >= ( 1ull << 30 ) || primsIdxCount >= ( 1ull << 30 ) || trianglesCount >= ( 1ull << 30 ) )
+		return 2;
+	for ( uint64_t i = 0; i < trianglesCount; ++i )
+		if ( tris[i].pV0 >= vertexCount || tris[i].pV1 >= vertexCount || tris[i].pV2 >= vertexCount )
+			return 3;
+	memset( out, 0, sizeof( *out ) );
+	out->bbox = *bbox;
+	out->nNodes = nodesCount;
+	out->nRecs = primsIdxCount;
+	out->nTris = trianglesCount;
+	out->nodes = (rt_hip_kdnode *) malloc( sizeof( rt_hip_kdnode ) * nodesCount );
+	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( primsIdxCount ? primsIdxCount : 1 ) );
+	out->shade = (rt_hip_trishade *) malloc( sizeof( rt_hip_trishade ) * ( trianglesCount ? trianglesCount : 1 ) );
+	std::vector<uint32_t> order( primsIdxCount ? primsIdxCount : 1 );
+	std::vector<int> depth( nodesCount, 0 );
+	uint64_t nextRef = 0;
+	int deepest = 0;
+	for ( uint64_t i = 0; i < nodesCount; ++i )
+	{
+		const rt_cl_kdtree_node &s = nodes[i];
+		deepest = std::max( deepest, depth[i] );
+		if ( s.isLast )
+		{
+			// leaf lists must follow each other in node order, as the reference packs them
+			if ( s.prims != nextRef || s.prims + s.primsCount > primsIdxCount )
+			{
+				rt_kdtree_flat_release( out );
+				return 5;
+			}
+			out->nodes[i].a = (uint32_t) s.prims;
+			out->nodes[i].b = ( (uint32_t) s.primsCount << 2 ) | 3u;
+			nextRef += s.primsCount;
+		}
+		else
+		{
+			if ( s.leftNode != i + 1 || s.rightNode <= i + 1 || s.rightNode >= nodesCount || (unsigned) s.axis > 2u )
+			{
+				rt_kdtree_flat_release( out );
+				return 6;
+			}
+			memcpy( &out->nodes[i].a, &s.sep, 4 );
+			out->nodes[i].b = ( (uint32_t) s.rightNode << 2 ) | (uint32_t) s.axis;
+			depth[i + 1] = depth[s.rightNode] = depth[i] + 1;
+		}
+	}
+	for ( uint64_t i = 0; i < primsIdxCount; ++i )
+	{
+		if ( primsIdx[i] >= trianglesCount )
+		{
+			rt_kdtree_flat_release( out );
+			return 7;
+		}
+		order[i] = (uint32_t) primsIdx[i];
+	}
+	out->depth = deepest;
+	fill_records( verts, tris, trianglesCount, order.data(), primsIdxCount, out->recs, out->shade, 1 );
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// reference-signature builder entry points (pointer tree, malloc'ed lists)
+// ---------------------------------------------------------------------------
+
+static inline float axis_of( const rt_vector3 &p, int ax ) { return ax == 0 ? p.x : ax == 1 ? p.y : p.z; }
+
+extern "C" void rt_kdtree_compute_sah( rt_ulong *memTp, rt_triangle *memTr, rt_vertex *memVer, rt_ulong primsCount,
+	RT_AXIS axis, rt_box *pBox, rt_ulong *primsCountL, rt_ulong *primsCountR, float *pSep )
+{
+	if ( !memTp || !memTr || !memVer || !pBox || !primsCountL || !primsCountR || !pSep )
+		exit( -1 );
+	uint64_t l = 0, r = 0;
+	float sep = 0.0f;
+	sah_sweep( primsCount, (int) axis, *pBox, [&]( uint64_t j, float &a, float &b ) {
+		const rt_triangle &t = memTr[memTp[j]];
+		tri_extent( axis_of( memVer[t.pV0].pos, axis ), axis_of( memVer[t.pV1].pos, axis ),
+			axis_of( memVer[t.pV2].pos, axis ), a, b );
+	}, l, r, sep );
+	*primsCountL = l;
+	*primsCountR = r;
+	*pSep = sep;
+}
+
+extern "C" rt_kdtree_count_info rt_kdtree_make_childs( rt_vertex *memVer, rt_triangle *memTr, rt_kdtree_node *pNode,
+	rt_box *bbox, int depth )
+{
+	if ( !memVer || !memTr || !pNode || !bbox )
+		exit( -1 );
+	rt_kdtree_count_info info;
+	if ( pNode->primsCount <= MAX_PRIMS_IN_NODE || depth == MAX_DEPTH )
+	{
+		pNode->isLast = 1;
+		pNode->leftNode = pNode->rightNode = NULL;
+		info.primsCount = pNode->primsCount;
+		info.nodesCount = 1;
+		return info;
+	}
+	pNode->isLast = 0;
+	const int ax = split_axis( *bbox );
+	pNode->axis = (RT_AXIS) ax;
+	pNode->leftNode = (rt_kdtree_node *) malloc( sizeof( rt_kdtree_node ) );
+	pNode->rightNode = (rt_kdtree_node *) malloc( sizeof( rt_kdtree_node ) );
+	rt_kdtree_compute_sah( pNode->prims, memTr, memVer, pNode->primsCount, pNode->axis, bbox,
+		&pNode->leftNode->primsCount, &pNode->rightNode->primsCount, &pNode->sep );
+	pNode->leftNode->prims = (rt_ulong *) malloc( sizeof( rt_ulong ) * ( pNode->leftNode->primsCount + 1 ) );
+	pNode->rightNode->prims = (rt_ulong *) malloc( sizeof( rt_ulong ) * ( pNode->rightNode->primsCount + 1 ) );
+	rt_ulong j = 0, k = 0;
+	for ( rt_ulong i = 0; i < pNode->primsCount; ++i )
+	{
+		const rt_triangle &t = memTr[pNode->prims[i]];
+		float mn, mx;
+		tri_extent( axis_of( memVer[t.pV0].pos, ax ), axis_of( memVer[t.pV1].pos, ax ), axis_of( memVer[t.pV2].pos, ax ), mn, mx );
+		if ( mn < pNode->sep ) pNode->leftNode->prims[j++] = pNode->prims[i];
+		if ( mx > pNode->sep ) pNode->rightNode->prims[k++] = pNode->prims[i];
+	}
+	free( pNode->prims );
+	pNode->prims = NULL;
+	rt_box bl, br;
+	child_boxes( *bbox, ax, pNode->sep, bl, br );
+	rt_kdtree_count_info a = rt_kdtree_make_childs( memVer, memTr, pNode->leftNode, &bl, depth + 1 );
+	rt_kdtree_count_info b = rt_kdtree_make_childs( memVer, memTr, pNode->rightNode, &br, depth + 1 );
+	info.primsCount = a.primsCount + b.primsCount;
+	info.nodesCount = a.nodesCount + b.nodesCount + 1;
+	return info;
+}
+
+// Flattens and frees the pointer tree.  Like the reference (:860-912) the
+// root and every inner node are freed; unlike it, leaf nodes are freed too.
+extern "C" rt_kdtree_count_info rt_kdtree_pack_to_buffer( rt_cl_kdtree_node *pNodeBuf, rt_ulong *pPrimsIdxBuf,
+	rt_kdtree_node *pNode, rt_ulong writePos, rt_ulong primsWritePos )
+{
+	if ( !pNodeBuf || !pNode )
+		exit( -1 );
+	rt_kdtree_count_info info;
+	pNodeBuf[writePos].isLast = pNode->isLast;
+	if ( pNode->isLast )
+	{
+		info.nodesCount = 1;
+		info.primsCount = pNode->primsCount;
+		pNodeBuf[writePos].primsCount = pNode->primsCount;
+		pNodeBuf[writePos].prims = primsWritePos;
+		if ( pNode->primsCount && pPrimsIdxBuf )
+			memcpy( pPrimsIdxBuf + primsWritePos, pNode->prims, sizeof( rt_ulong ) * pNode->primsCount );
+		free( pNode->prims );
+		if ( writePos != 0 )
+			free( pNode );
+		return info;
+	}
+	rt_kdtree_count_info l = rt_kdtree_pack_to_buffer( pNodeBuf, pPrimsIdxBuf, pNode->leftNode, writePos + 1, primsWritePos );
+	rt_kdtree_count_info r = rt_kdtree_pack_to_buffer( pNodeBuf, pPrimsIdxBuf, pNode->rightNode,
+		writePos + l.nodesCount + 1, primsWritePos + l.primsCount );
+	pNodeBuf[writePos].sep = pNode->sep;
+	pNodeBuf[writePos].axis = pNode->axis;
+	pNodeBuf[writePos].leftNode = writePos + 1;
+	pNodeBuf[writePos].rightNode = writePos + l.nodesCount + 1;
+	free( pNode );
+	info.nodesCount = l.nodesCount + r.nodesCount + 1;
+	info.primsCount = l.primsCount + r.primsCount;
+	return info;
+}

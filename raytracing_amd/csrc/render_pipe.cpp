@@ -1,0 +1,418 @@
+// Render-pipe API of include/rt_funcs_render_pipe.h on top of the HIP layer.
+//
+// Scene data added through rt_render_pipe_add_* is kept in host arrays (the
+// reference wrote it to OpenCL buffers and read triangles and vertices back
+// for every tree build, rt_funcs_render_pipe.c:1106-1112); rt_render_pipe_draw
+// builds the kd-tree straight into the HBM layout, uploads what changed and
+// launches the kernels.  With RT_PARAM_TREE_CACHE the tree and its device
+// copy are reused while the geometry bytes are unchanged.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rt_funcs_render_pipe.h"
+#include "rt_kdtree.h"
+
+char *rt_cl_include_path = nullptr;
+char *rt_cl_raytrace_kernel_path = nullptr;
+
+struct rt_pipe_impl
+{
+	rt_hip_ctx *hip = nullptr;
+	std::vector<rt_vertex> verts;
+	std::vector<rt_triangle> tris;
+	std::vector<rt_sphere> spheres;
+	std::vector<rt_point_light> lights;
+	std::vector<rt_material> mats;
+	rt_camera cam;
+	int maxDepth = MAX_DEPTH, maxPrims = MAX_PRIMS_IN_NODE, stackSize = STACK_SIZE;
+	int buildThreads = 0, treeCache = 0;
+	int bandH = 16, nParts = 1, part = 0;
+	bool matsDirty = true;
+	bool haveTree = false;
+	uint64_t geomHash = 0, geomBytes = 0;
+	rt_kdtree_flat lastInfo;          // counts of the tree on the device (arrays released)
+};
+
+static int g_device = 0;
+
+static void die_hip( const char *what )
+{
+	fprintf( stderr, "rt: %s: %s\n", what, rt_hip_last_error() );
+	fflush( stderr );
+	exit( -3 );
+}
+
+static rt_pipe_impl *impl_of( rt_render_pipe *pRp )
+{
+	if ( !pRp || !pRp->impl )
+		exit( -1 );
+	return pRp->impl;
+}
+
+// FNV-1a over 8-byte words: cheap change detector for the tree cache
+static uint64_t hash_bytes( const void *p, size_t n, uint64_t h )
+{
+	const uint64_t *w = (const uint64_t *) p;
+	size_t k = n / 8;
+	for ( size_t i = 0; i < k; ++i )
+	{
+		h ^= w[i];
+		h *= 1099511628211ull;
+	}
+	const unsigned char *t = (const unsigned char *) p + 8 * k;
+	for ( size_t i = 0; i < n - 8 * k; ++i )
+	{
+		h ^= t[i];
+		h *= 1099511628211ull;
+	}
+	return h;
+}
+
+extern "C" {
+
+// derives the executable's directory, as the reference's rt_init (:3-19) does
+// to find its kernel sources; nothing is loaded from it here
+void rt_init( char *path )
+{
+	if ( !path )
+		exit( -1 );
+	size_t cut = strlen( path );
+	while ( cut > 0 && path[cut - 1] != '/' )
+		--cut;
+	if ( cut > 0 )
+		--cut;                       // drop the slash itself
+	static const char tail[] = "/CL/rt_raytrace.cl";
+	free( rt_cl_include_path );
+	free( rt_cl_raytrace_kernel_path );
+	rt_cl_include_path = (char *) malloc( cut + 1 );
+	rt_cl_raytrace_kernel_path = (char *) malloc( cut + sizeof( tail ) );
+	memcpy( rt_cl_include_path, path, cut );
+	rt_cl_include_path[cut] = '\0';
+	memcpy( rt_cl_raytrace_kernel_path, path, cut );
+	memcpy( rt_cl_raytrace_kernel_path + cut, tail, sizeof( tail ) );
+}
+
+void rt_render_pipe_select_device( int device ) { g_device = device; }
+
+void rt_init_buffers( rt_render_pipe *pRp )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	pRp->primBlocks = pRp->primDecsBlocks = pRp->lightBlocks = pRp->lightDecsBlocks = 1;
+	pRp->triangleBlocks = pRp->vertexBlocks = pRp->materialBlocks = 1;
+	pRp->primsEnd = pRp->lightsEnd = 0;
+	pRp->primsCount = pRp->lightsCount = pRp->trianglesCount = pRp->vertexCount = 0;
+	im->verts.clear();
+	im->tris.clear();
+	im->spheres.clear();
+	im->lights.clear();
+	im->mats.assign( MATERIALS_IN_BLOCK, rt_material() );
+	memset( im->mats.data(), 0, sizeof( rt_material ) * im->mats.size() );
+	im->matsDirty = true;
+}
+
+void rt_render_pipe_create( rt_render_pipe *pRp, int w, int h )
+{
+	if ( !pRp )
+		exit( -1 );
+	memset( pRp, 0, sizeof( *pRp ) );
+	pRp->impl = new rt_pipe_impl();
+	memset( &pRp->impl->lastInfo, 0, sizeof( rt_kdtree_flat ) );
+	pRp->impl->hip = rt_hip_create( g_device );
+	if ( !pRp->impl->hip )
+		die_hip( "cannot create the HIP context" );
+	rt_init_buffers( pRp );
+	{
+		rt_camera &c = pRp->impl->cam;
+		memset( &c, 0, sizeof( c ) );
+		c.world._11 = c.world._22 = c.world._33 = c.world._44 = 1.0f;
+		c.viewToPersp = c.world;
+	}
+	pRp->screenData = NULL;
+	rt_render_pipe_set_image_size( pRp, w, h );
+}
+
+void rt_render_pipe_set_image_size( rt_render_pipe *pRp, int w, int h )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( rt_hip_set_image( im->hip, w, h ) )
+		die_hip( "rt_render_pipe_set_image_size" );
+	free( pRp->screenData );
+	pRp->screenData = (rt_argb *) malloc( sizeof( rt_argb ) * (size_t) w * (size_t) h );
+	pRp->w = w;
+	pRp->h = h;
+}
+
+void rt_render_pipe_reset_blocks( rt_render_pipe *pRp )
+{
+	impl_of( pRp );
+	rt_init_buffers( pRp );
+}
+
+void rt_render_pipe_set_camera( rt_render_pipe *pRp, rt_camera *pFr )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !pFr )
+		exit( -1 );
+	im->cam = *pFr;
+}
+
+void rt_render_pipe_get_camera( rt_render_pipe *pRp, rt_camera **ppC )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !ppC )
+		exit( -1 );
+	*ppC = &im->cam;
+}
+
+void rt_render_pipe_free_camera( rt_render_pipe *pRp, rt_camera *pC )
+{
+	impl_of( pRp );
+	if ( !pC )
+		exit( -1 );
+	// the camera is read at the next draw; nothing to write back
+}
+
+// block accounting of rt_add_block (:186-207): grow by whole blocks
+static void grow_blocks( rt_ulong *blocks, size_t blockSize, size_t needed )
+{
+	rt_ulong add = needed / blockSize;
+	*blocks += add ? add : 1;
+}
+
+void rt_render_pipe_add_primitive( rt_render_pipe *pRp, void *pPrim, RT_PRIMITIVE_TYPE pt )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !pPrim )
+		exit( -1 );
+	if ( ( pRp->primsCount + 1 ) > PRIMS_IN_BLOCK * pRp->primDecsBlocks )
+		grow_blocks( &pRp->primDecsBlocks, sizeof( rt_prim_desc ) * PRIMS_IN_BLOCK, sizeof( rt_prim_desc ) );
+	if ( pt == RT_PT_SPHERE )
+	{
+		if ( ( pRp->primsEnd + sizeof( rt_sphere ) ) >= (size_t) PRIMS_BLOCK_SIZE * pRp->primBlocks )
+			grow_blocks( &pRp->primBlocks, PRIMS_BLOCK_SIZE, sizeof( rt_sphere ) );
+		im->spheres.push_back( *(const rt_sphere *) pPrim );
+		pRp->primsEnd += sizeof( rt_sphere );
+		++pRp->primsCount;
+	}
+	// Other primitive types are ignored: the reference records a descriptor
+	// for them but never uploads or intersects them (:234-256).
+}
+
+void rt_render_pipe_add_triangles( rt_render_pipe *pRp, rt_vertex *pV, rt_triangle *pTr, rt_ulong vOffset,
+	rt_ulong tOffset, rt_ulong vCount, rt_ulong tCount, rt_ulong tGroup )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !pV || !pTr )
+		exit( -1 );
+	if ( ( pRp->trianglesCount + tCount ) >= (rt_ulong) TRIANGLES_IN_BLOCK * pRp->triangleBlocks )
+		grow_blocks( &pRp->triangleBlocks, TRIANGLES_IN_BLOCK * sizeof( rt_triangle ), sizeof( rt_triangle ) * tCount );
+	if ( ( pRp->vertexCount + vCount ) >= (rt_ulong) VERTEX_IN_BLOCK * pRp->vertexBlocks )
+		grow_blocks( &pRp->vertexBlocks, VERTEX_IN_BLOCK * sizeof( rt_vertex ), sizeof( rt_vertex ) * vCount );
+
+	const rt_ulong base = pRp->vertexCount;
+	im->verts.insert( im->verts.end(), pV + vOffset, pV + vOffset + vCount );
+	im->tris.reserve( im->tris.size() + tCount );
+	for ( rt_ulong i = 0; i < tCount; ++i )
+	{
+		const rt_triangle &s = pTr[i + tOffset];
+		rt_triangle t;
+		t.pV0 = base + s.pV0 - vOffset;
+		t.pV1 = base + s.pV1 - vOffset;
+		t.pV2 = base + s.pV2 - vOffset;
+		t.mat = tGroup;
+		im->tris.push_back( t );
+	}
+	pRp->trianglesCount += tCount;
+	pRp->vertexCount += vCount;
+}
+
+void rt_render_pipe_add_material( rt_render_pipe *pRp, rt_material *pMat, unsigned long int ind )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !pMat )
+		exit( -1 );
+	while ( ind >= (unsigned long) MATERIALS_IN_BLOCK * pRp->materialBlocks )
+		grow_blocks( &pRp->materialBlocks, MATERIALS_IN_BLOCK * sizeof( rt_material ), sizeof( rt_material ) );
+	if ( im->mats.size() < (size_t) MATERIALS_IN_BLOCK * pRp->materialBlocks )
+	{
+		rt_material z;
+		memset( &z, 0, sizeof( z ) );
+		im->mats.resize( (size_t) MATERIALS_IN_BLOCK * pRp->materialBlocks, z );
+	}
+	if ( memcmp( &im->mats[ind], pMat, sizeof( rt_material ) ) != 0 )
+	{
+		im->mats[ind] = *pMat;
+		im->matsDirty = true;
+	}
+}
+
+void rt_render_pipe_add_light( rt_render_pipe *pRp, void *pLight, RT_LIGHT_TYPE lt )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !pLight )
+		exit( -1 );
+	if ( ( pRp->lightsCount + 1 ) > LIGHTS_IN_BLOCK * pRp->lightDecsBlocks )
+		grow_blocks( &pRp->lightDecsBlocks, sizeof( rt_light_desc ) * LIGHTS_IN_BLOCK, sizeof( rt_light_desc ) );
+	if ( lt == RT_LT_POINT )
+	{
+		if ( ( pRp->lightsEnd + sizeof( rt_point_light ) ) >= (size_t) LIGHTS_BLOCK_SIZE * pRp->lightBlocks )
+			grow_blocks( &pRp->lightBlocks, LIGHTS_BLOCK_SIZE, sizeof( rt_point_light ) );
+		im->lights.push_back( *(const rt_point_light *) pLight );
+		pRp->lightsEnd += sizeof( rt_point_light );
+		++pRp->lightsCount;
+	}
+	// directed lights are declared by the reference but never shaded (:460)
+}
+
+void rt_render_pipe_set_param( rt_render_pipe *pRp, int key, int value )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	switch ( key )
+	{
+	case RT_PARAM_STACK_SIZE:
+		if ( rt_hip_set_param( im->hip, key, value ) )
+			die_hip( "rt_render_pipe_set_param" );
+		im->stackSize = value;
+		break;
+	case RT_PARAM_MAX_DEPTH:
+		if ( value < 0 || value > RT_HIP_MAX_TREE_DEPTH ) { fprintf( stderr, "rt: RT_PARAM_MAX_DEPTH out of range\n" ); exit( -3 ); }
+		im->maxDepth = value;
+		im->haveTree = false;
+		break;
+	case RT_PARAM_MAX_PRIMS_IN_NODE:
+		if ( value < 1 ) { fprintf( stderr, "rt: RT_PARAM_MAX_PRIMS_IN_NODE out of range\n" ); exit( -3 ); }
+		im->maxPrims = value;
+		im->haveTree = false;
+		break;
+	case RT_PARAM_BUILD_THREADS: im->buildThreads = value; break;
+	case RT_PARAM_TREE_CACHE: im->treeCache = value; break;
+	default:
+		fprintf( stderr, "rt: unknown parameter %d\n", key );
+		exit( -3 );
+	}
+}
+
+void rt_render_pipe_set_tile( rt_render_pipe *pRp, int bandH, int nParts, int part )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( rt_hip_set_tile( im->hip, bandH, nParts, part ) )
+		die_hip( "rt_render_pipe_set_tile" );
+	im->bandH = bandH; im->nParts = nParts; im->part = part;
+}
+
+rt_hip_ctx *rt_render_pipe_hip( rt_render_pipe *pRp ) { return impl_of( pRp )->hip; }
+
+void rt_kdtree_build( rt_render_pipe *pRp, rt_box *pBoundingBox, rt_cl_kdtree_node **nodes, rt_ulong *nodesCount,
+	rt_ulong **primsIdx, rt_ulong *primsIdxCount )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	if ( !pBoundingBox || !nodes || !nodesCount || !primsIdx || !primsIdxCount )
+		exit( -1 );
+	rt_kdtree_flat t;
+	int rc = rt_kdtree_build_flat( im->verts.data(), im->tris.data(), im->verts.size(), im->tris.size(),
+		im->maxDepth, im->maxPrims, im->buildThreads, &t );
+	if ( rc )
+	{
+		fprintf( stderr, "rt: kd-tree build failed (%d)\n", rc );
+		exit( -3 );
+	}
+	*pBoundingBox = t.bbox;
+	uint64_t nn = 0, ni = 0;
+	rt_kdtree_flat_expand( &t, nodes, &nn, primsIdx, &ni );
+	*nodesCount = nn;
+	*primsIdxCount = ni;
+	rt_kdtree_flat_release( &t );
+}
+
+// upload everything the kernels read and enqueue one frame
+static void submit_frame( rt_render_pipe *pRp, void *d_out )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+
+	uint64_t h = 1469598103934665603ull;
+	h = hash_bytes( im->verts.data(), im->verts.size() * sizeof( rt_vertex ), h );
+	h = hash_bytes( im->tris.data(), im->tris.size() * sizeof( rt_triangle ), h );
+	const uint64_t bytes = im->verts.size() * sizeof( rt_vertex ) + im->tris.size() * sizeof( rt_triangle );
+	const bool reuse = im->treeCache && im->haveTree && h == im->geomHash && bytes == im->geomBytes;
+	if ( !reuse )
+	{
+		rt_kdtree_flat t;
+		int rc = rt_kdtree_build_flat( im->verts.data(), im->tris.data(), im->verts.size(), im->tris.size(),
+			im->maxDepth, im->maxPrims, im->buildThreads, &t );
+		if ( rc )
+		{
+			fprintf( stderr, "rt: kd-tree build failed (%d)\n", rc );
+			exit( -3 );
+		}
+		if ( rt_hip_upload_tree( im->hip, t.nodes, t.nNodes, t.recs, t.nRecs, t.shade, t.nTris, &t.bbox, t.depth ) )
+			die_hip( "tree upload" );
+		im->lastInfo = t;
+		im->lastInfo.nodes = nullptr; im->lastInfo.recs = nullptr; im->lastInfo.shade = nullptr;
+		rt_kdtree_flat_release( &t );
+		im->haveTree = true;
+		im->geomHash = h;
+		im->geomBytes = bytes;
+	}
+	if ( im->matsDirty )
+	{
+		if ( rt_hip_upload_materials( im->hip, im->mats.data(), im->mats.size() ) )
+			die_hip( "material upload" );
+		im->matsDirty = false;
+	}
+	if ( rt_hip_upload_spheres( im->hip, im->spheres.data(), im->spheres.size() ) ) die_hip( "sphere upload" );
+	if ( rt_hip_upload_lights( im->hip, im->lights.data(), im->lights.size() ) ) die_hip( "light upload" );
+	if ( rt_hip_set_camera( im->hip, &im->cam ) ) die_hip( "camera" );
+	if ( rt_hip_render( im->hip, d_out, 0 ) ) die_hip( "render" );
+}
+
+// per-frame reset of :1226-1231: geometry, spheres and lights are consumed
+static void consume_scene( rt_render_pipe *pRp )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	im->verts.clear();
+	im->tris.clear();
+	im->spheres.clear();
+	im->lights.clear();
+	pRp->trianglesCount = pRp->vertexCount = 0;
+	pRp->lightsCount = pRp->primsCount = 0;
+	pRp->primsEnd = pRp->lightsEnd = 0;
+}
+
+rt_argb *rt_render_pipe_draw( rt_render_pipe *pRp )
+{
+	rt_pipe_impl *im = impl_of( pRp );
+	submit_frame( pRp, nullptr );
+	// rows rendered by this pipe land at the top of screenData (all of it
+	// unless a tile split is set)
+	if ( rt_hip_read_frame( im->hip, pRp->screenData ) )
+		die_hip( "frame read-back" );
+	consume_scene( pRp );
+	return pRp->screenData;
+}
+
+void rt_render_pipe_draw_device( rt_render_pipe *pRp, void *d_out )
+{
+	if ( !d_out )
+		exit( -1 );
+	submit_frame( pRp, d_out );
+	consume_scene( pRp );
+}
+
+void rt_render_pipe_cleanup( rt_render_pipe *pRp )
+{
+	if ( !pRp )
+		exit( -1 );
+	free( pRp->screenData );
+	pRp->screenData = NULL;
+	if ( pRp->impl )
+	{
+		rt_hip_destroy( pRp->impl->hip );
+		delete pRp->impl;
+		pRp->impl = nullptr;
+	}
+}
+
+} // extern "C"

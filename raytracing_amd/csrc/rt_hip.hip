@@ -1,0 +1,1269 @@
+// HIP layer + CDNA4 kernels of the ray tracer (gfx950 only).
+//
+// One frame is a short sequence of persistent wave64 kernels over explicit
+// work lists in HBM instead of one per-pixel megakernel:
+//
+//   for slot k = 0 .. STACK_SIZE-1            (slot = index in the pixel's ray list)
+//     k_closest<k>  ray list k  -> closest hit (spheres brute force + kd tree)
+//                   misses finish their slot, hits are COMPACTED into a hit list
+//     k_shade<k>    hit list k  -> hit point, normal, one shadow traversal per
+//                   light, Phong terms; child rays are appended (wave-aggregated
+//                   atomics) to the ray lists of the slots they occupy
+//   k_fold          per pixel: fold child colours into parents back to front,
+//                   clamp, truncate to 8-bit BGRA
+//
+// This is the reference's iterative ray tree (CL/rt_funcs_primitives.cl:584-728)
+// turned inside out: the reference walks the <= 6 slots of ONE pixel in a
+// private array; here every launch processes slot k of ALL pixels, so lanes
+// are always packed with live rays, and the slot a child lands in is the same
+// as in the reference because slots of a pixel are still filled in slot order.
+//
+// Waves pull 64-entry chunks from a device-side counter until the list is
+// empty (persistent workers); the kd traversal stack lives in LDS
+// (RT_LDS_STACK entries per lane, lane-interleaved, conflict free) and spills
+// to a per-lane strip of HBM beyond that.
+//
+// Arithmetic is fp32 without contraction, in the operand order of the
+// reference's OpenCL source, so hit ids and barycentrics agree bit for bit
+// with the CPU restatement used by the tests.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rt_hip.h"
+
+#define RT_BLOCK      256
+#define RT_LDS_STACK  16
+#define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
+#define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
+
+// ---------------------------------------------------------------------------
+// device-side data
+// ---------------------------------------------------------------------------
+
+struct f3 { float x, y, z; };
+
+struct DevScene
+{
+	const uint2  *nodes;      // rt_hip_kdnode
+	const float4 *recs;       // rt_hip_trirec as 3 x float4
+	const float4 *shade;      // rt_hip_trishade as 3 x float4
+	const rt_material *mats;
+	const float4 *spheres;    // (pos.xyz, rad)
+	const uint32_t *sphereMat;
+	const float4 *lights;     // 3 x float4: (col b,g,r,a) (pos.xyz,_) (rad,_,_,_)
+	float bbC[3], bbE[3];
+	float world[16], vtp[16];
+	int nSpheres, nLights;
+	int w, h;                 // full image
+	int localH, bandH, nParts, part;
+	int stackSize;
+};
+
+struct Counters
+{
+	uint32_t rayCount[RT_MAX_SLOTS];      // entries in ray list k (k >= 1)
+	uint32_t headClosest[RT_MAX_SLOTS];   // chunk dispenser of k_closest
+	uint32_t hitCount[RT_MAX_SLOTS];      // entries in the hit list of slot k
+	uint32_t headShade[RT_MAX_SLOTS];     // chunk dispenser of k_shade
+	unsigned long long nodeVisits, triTests, spillPushes, maxStack;
+};
+
+struct Work
+{
+	Counters *ctr;
+	float4 *rayA, *rayB, *rayC, *rayD;    // [(slot-1) * npix + entry]
+	float4 *hitA;                         // (entry, t, u, v)
+	uint2  *hitB;                         // (id | sphere flag, b)
+	float4 *res;                          // [slot * npix + pix] (col rgb, parent slot)
+	float4 *fac;                          // [slot * npix + pix] weight of this slot in its parent
+	uint32_t *stackPos;                   // last used slot of each pixel
+	int32_t *hitId;                       // optional primary hit ids
+	uint2  *spill;                        // traversal stack overflow
+	uint32_t npix, tilesX, nChunks0, spillStride;
+};
+
+struct Ray { f3 src, dest, inv; };
+
+#define DEVI __device__ __forceinline__
+
+DEVI f3 F3( float x, float y, float z ) { f3 r = { x, y, z }; return r; }
+DEVI f3 add3( f3 a, f3 b ) { return F3( a.x + b.x, a.y + b.y, a.z + b.z ); }
+DEVI f3 sub3( f3 a, f3 b ) { return F3( a.x - b.x, a.y - b.y, a.z - b.z ); }
+DEVI f3 mul3( f3 a, float s ) { return F3( a.x * s, a.y * s, a.z * s ); }
+DEVI f3 div3( f3 a, float s ) { return F3( a.x / s, a.y / s, a.z / s ); }
+DEVI f3 rcp3( f3 a ) { return F3( 1.0f / a.x, 1.0f / a.y, 1.0f / a.z ); }
+DEVI float dot3( f3 a, f3 b ) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEVI f3 cross3( f3 a, f3 b ) { return F3( a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x ); }
+DEVI float len3( f3 a ) { return sqrtf( dot3( a, a ) ); }
+DEVI f3 norm3( f3 a ) { return div3( a, len3( a ) ); }
+DEVI float cl_max( float x, float y ) { return ( x < y ) ? y : x; }
+// reference CL/rt_funcs_math.cl:102-105 (NaN -> lower bound)
+DEVI float clampf( float f, float b, float e ) { return ( f > b ) ? ( ( f < e ) ? f : e ) : b; }
+DEVI f3 clamp01( f3 c ) { return F3( clampf( c.x, 0.0f, 1.0f ), clampf( c.y, 0.0f, 1.0f ), clampf( c.z, 0.0f, 1.0f ) ); }
+// colours are kept as f3 (r,g,b); every colour op clamps (CL/rt_funcs_math.cl:149-185)
+DEVI f3 col_mult( f3 a, f3 b ) { return clamp01( F3( a.x * b.x, a.y * b.y, a.z * b.z ) ); }
+DEVI f3 col_add( f3 a, f3 b ) { return clamp01( add3( a, b ) ); }
+DEVI f3 col_scale( f3 a, float s ) { return clamp01( mul3( a, s ) ); }
+DEVI f3 rgb_of( const rt_color &c ) { return F3( c.r, c.g, c.b ); }
+// CL/rt_funcs_math.cl:119-124
+DEVI f3 reflect3( f3 v, f3 n ) { float d = dot3( v, n ); return sub3( v, mul3( mul3( n, 2.0f ), d ) ); }
+DEVI float minF( float a, float b ) { return ( a < b ) ? a : b; }
+DEVI float maxF( float a, float b ) { return ( a > b ) ? a : b; }
+
+DEVI uint32_t lane_id() { return threadIdx.x & 63u; }
+DEVI uint32_t wave_bcast( uint32_t v ) { return (uint32_t) __builtin_amdgcn_readfirstlane( (int) v ); }
+DEVI uint32_t lanes_below( unsigned long long mask )
+{
+	return __builtin_amdgcn_mbcnt_hi( (uint32_t) ( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t) mask, 0u ) );
+}
+
+// wave-aggregated append: lanes with `want` receive consecutive indices
+DEVI uint32_t wave_append( uint32_t *counter, bool want )
+{
+	unsigned long long m = __ballot( want );
+	uint32_t base = 0;
+	if ( m == 0ull )
+		return 0;
+	if ( lane_id() == (uint32_t) __ffsll( (long long) m ) - 1u )
+		base = atomicAdd( counter, (uint32_t) __popcll( m ) );
+	base = __shfl( base, __ffsll( (long long) m ) - 1 );
+	return base + lanes_below( m );
+}
+
+struct StackRef { uint2 *lds; uint2 *spill; uint32_t stride; };
+
+struct Tally { uint32_t nodes, tris, spills, maxSp; };
+
+template <bool STATS>
+DEVI void stack_push( const StackRef &s, int sp, uint32_t node, float tFar, Tally &tl )
+{
+	uint2 v = make_uint2( node, __float_as_uint( tFar ) );
+	if ( sp < RT_LDS_STACK )
+		s.lds[sp * RT_BLOCK] = v;
+	else
+	{
+		s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride] = v;
+		if ( STATS ) ++tl.spills;
+	}
+	if ( STATS && (uint32_t) ( sp + 1 ) > tl.maxSp ) tl.maxSp = sp + 1;
+}
+DEVI uint2 stack_pop( const StackRef &s, int sp )
+{
+	return ( sp < RT_LDS_STACK ) ? s.lds[sp * RT_BLOCK] : s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride];
+}
+
+// ---------------------------------------------------------------------------
+// intersections (reference CL/rt_intersection.cl)
+// ---------------------------------------------------------------------------
+
+// :7-64
+DEVI int ray_sphere( const Ray &r, float4 s, float &t )
+{
+	f3 tmp = sub3( r.src, F3( s.x, s.y, s.z ) );
+	float b = dot3( r.dest, tmp );
+	b *= 2.0f;
+	float c = dot3( tmp, tmp );
+	c -= s.w * s.w;
+	float d = b * b - 4 * c;
+	if ( d < 0.0f )
+		return 0;
+	d = sqrtf( d );
+	float x1 = ( -b - d ) / 2.0f;
+	float x2 = ( -b + d ) / 2.0f;
+	if ( x2 < 0.0f )
+		return 0;
+	if ( x1 < 0.0f )
+	{
+		t = x2;
+		return -1;
+	}
+	t = x1;
+	return 1;
+}
+
+// :110-154 with e1 / e2 taken from the leaf record
+DEVI bool ray_tri( const Ray &r, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v )
+{
+	f3 p = cross3( r.dest, e2 );
+	float det = dot3( e1, p );
+	if ( det == 0.0f )
+		return false;
+	det = 1.0f / det;
+	f3 dist = sub3( r.src, v0 );
+	u = dot3( p, dist ) * det;
+	if ( ( u < 0.0f ) || ( u > 1.0f ) )
+		return false;
+	f3 q = cross3( dist, e1 );
+	v = dot3( q, r.dest ) * det;
+	if ( ( v < 0.0f ) || ( v + u > 1.0f ) )
+		return false;
+	t = dot3( q, e2 ) * det;
+	return t > 0.0f;
+}
+
+// :156-200
+DEVI bool box_ray( const DevScene &S, const Ray &r, float &tNear, float &tFar )
+{
+	float t1 = ( S.bbC[0] - S.bbE[0] - r.src.x ) * r.inv.x;
+	float t2 = ( S.bbC[0] + S.bbE[0] - r.src.x ) * r.inv.x;
+	float t3 = ( S.bbC[1] - S.bbE[1] - r.src.y ) * r.inv.y;
+	float t4 = ( S.bbC[1] + S.bbE[1] - r.src.y ) * r.inv.y;
+	float t5 = ( S.bbC[2] - S.bbE[2] - r.src.z ) * r.inv.z;
+	float t6 = ( S.bbC[2] + S.bbE[2] - r.src.z ) * r.inv.z;
+	tNear = maxF( maxF( minF( t1, t2 ), minF( t3, t4 ) ), minF( t5, t6 ) );
+	tFar = minF( minF( maxF( t1, t2 ), maxF( t3, t4 ) ), maxF( t5, t6 ) );
+	if ( tFar < 0 )
+		return false;
+	if ( tNear > tFar )
+		return false;
+	return true;
+}
+
+DEVI void load_rec( const float4 *recs, uint32_t i, f3 &v0, f3 &e1, f3 &e2, uint32_t &tri, uint32_t &mat )
+{
+	const float4 *p = recs + 3u * (size_t) i;
+	float4 a = p[0], b = p[1], c = p[2];
+	v0 = F3( a.x, a.y, a.z );
+	e1 = F3( a.w, b.x, b.y );
+	e2 = F3( b.z, b.w, c.x );
+	tri = __float_as_uint( c.y );
+	mat = __float_as_uint( c.z );
+}
+
+// inner-node step shared by both traversals (CL/rt_funcs_primitives.cl:185-251)
+template <bool STATS>
+DEVI uint32_t kd_inner( uint2 n, uint32_t cur, const Ray &r, float tNear, float &tFar,
+	const StackRef &st, int &sp, Tally &tl )
+{
+	uint32_t axis = n.y & 3u;
+	float sep = __uint_as_float( n.x );
+	float o = axis == 0u ? r.src.x : ( axis == 1u ? r.src.y : r.src.z );
+	float iv = axis == 0u ? r.inv.x : ( axis == 1u ? r.inv.y : r.inv.z );
+	float d = axis == 0u ? r.dest.x : ( axis == 1u ? r.dest.y : r.dest.z );
+	float tSplit = ( sep - o ) * iv;
+	uint32_t nearN = cur + 1u, farN = n.y >> 2;
+	if ( d < 0.0f )
+	{
+		uint32_t tmp = nearN;
+		nearN = farN;
+		farN = tmp;
+	}
+	if ( tSplit >= tFar )
+		return nearN;
+	if ( tSplit <= tNear )
+		return farN;
+	stack_push<STATS>( st, sp, farN, tFar, tl );
+	++sp;
+	tFar = tSplit;
+	return nearN;
+}
+
+// closest hit over the kd tree, CL/rt_funcs_primitives.cl:151-253 with the leaf
+// loop :74-111 inlined.  The per-leaf reset of the running distance while the
+// hit flag and the triangle id persist is the reference's behaviour.
+template <bool STATS>
+DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float &minT, float &minU,
+	float &minV, uint32_t &prN, int &nearestB, Tally &tl )
+{
+	float tNear, tFar;
+	minT = INFINITY;
+	if ( !box_ray( S, r, tNear, tFar ) )
+		return;
+	uint32_t cur = 0;
+	int sp = 0;
+	for ( ;; )
+	{
+		uint2 n = S.nodes[cur];
+		if ( STATS ) ++tl.nodes;
+		if ( ( n.y & 3u ) == 3u )
+		{
+			uint32_t cnt = n.y >> 2;
+			float lt = INFINITY;
+			for ( uint32_t i = 0; i < cnt; ++i )
+			{
+				f3 v0, e1, e2;
+				uint32_t tri, mat;
+				float t, u, v;
+				load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
+				if ( STATS ) ++tl.tris;
+				if ( ray_tri( r, v0, e1, e2, t, u, v ) && t < lt )
+				{
+					lt = t;
+					minU = u;
+					minV = v;
+					prN = tri;
+					nearestB = 1;
+				}
+			}
+			minT = lt;
+			if ( nearestB && ( minT < tFar ) )
+				return;
+			if ( !sp )
+				return;
+			--sp;
+			uint2 e = stack_pop( st, sp );
+			cur = e.x;
+			tNear = tFar;
+			tFar = __uint_as_float( e.y );
+		}
+		else
+			cur = kd_inner<STATS>( n, cur, r, tNear, tFar, st, sp, tl );
+	}
+}
+
+// shadow query: sum of the opacities of every triangle hit before the light,
+// CL/rt_funcs_primitives.cl:278-379 + :256-276.  Returns false (alpha
+// untouched) when the ray misses the scene box.
+template <bool STATS>
+DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d, float &alpha, Tally &tl )
+{
+	float tNear, tFar;
+	if ( !box_ray( S, r, tNear, tFar ) )
+		return false;
+	alpha = 0.0f;
+	uint32_t cur = 0;
+	int sp = 0;
+	for ( ;; )
+	{
+		uint2 n = S.nodes[cur];
+		if ( STATS ) ++tl.nodes;
+		if ( ( n.y & 3u ) == 3u )
+		{
+			uint32_t cnt = n.y >> 2;
+			for ( uint32_t i = 0; i < cnt; ++i )
+			{
+				f3 v0, e1, e2;
+				uint32_t tri, mat;
+				float t, u, v;
+				load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
+				if ( STATS ) ++tl.tris;
+				if ( ray_tri( r, v0, e1, e2, t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
+					alpha += S.mats[mat].color.a;
+			}
+			if ( !sp )
+				return true;
+			--sp;
+			uint2 e = stack_pop( st, sp );
+			cur = e.x;
+			tNear = tFar;
+			tFar = __uint_as_float( e.y );
+		}
+		else
+			cur = kd_inner<STATS>( n, cur, r, tNear, tFar, st, sp, tl );
+	}
+}
+
+// ---------------------------------------------------------------------------
+// rays
+// ---------------------------------------------------------------------------
+
+// camera ray of pixel (x, y) of the full image, CL/rt_raytrace.cl:27-28,60-79
+DEVI Ray primary_ray( const DevScene &S, int x, int y )
+{
+	float xTr = 2.0f / (float) ( S.w - 1 );
+	float yTr = 2.0f / (float) ( S.h - 1 );
+	const float *W = S.world, *P = S.vtp;
+	Ray r;
+	f3 s = F3( 0.0f, 0.0f, 0.0f );
+	f3 d = F3( xTr * (float) x - 1.0f, yTr * (float) y - 1.0f, 1.0f );
+	r.src = F3( W[0] * s.x + W[4] * s.y + W[8] * s.z + W[12],
+	            W[1] * s.x + W[5] * s.y + W[9] * s.z + W[13],
+	            W[2] * s.x + W[6] * s.y + W[10] * s.z + W[14] );
+	d = F3( P[0] * d.x + P[4] * d.y + P[8] * d.z, P[1] * d.x + P[5] * d.y + P[9] * d.z,
+	        P[2] * d.x + P[6] * d.y + P[10] * d.z );
+	d = F3( W[0] * d.x + W[4] * d.y + W[8] * d.z, W[1] * d.x + W[5] * d.y + W[9] * d.z,
+	        W[2] * d.x + W[6] * d.y + W[10] * d.z );
+	r.dest = norm3( d );
+	r.inv = rcp3( r.dest );
+	return r;
+}
+
+// entry e of slot 0 = lane (e & 63) of the 8x8 pixel tile (e >> 6)
+DEVI bool slot0_pixel( const DevScene &S, const Work &W, uint32_t e, int &x, int &yLocal, int &yGlobal )
+{
+	uint32_t tile = e >> 6, ln = e & 63u;
+	x = (int) ( ( tile % W.tilesX ) * 8u + ( ln & 7u ) );
+	yLocal = (int) ( ( tile / W.tilesX ) * 8u + ( ln >> 3 ) );
+	int band = yLocal / S.bandH;
+	yGlobal = ( band * S.nParts + S.part ) * S.bandH + ( yLocal - band * S.bandH );
+	return x < S.w && yLocal < S.localH && yGlobal < S.h;
+}
+
+struct RayEntry
+{
+	Ray ray;
+	uint32_t pix;
+	int parent, type;      // parent slot (-1 for slot 0), 1 = reflection, 0 = refraction
+	f3 coef;               // reflection: parent reflect rgb; refraction: parent color rgb * lightFalloff
+	f3 parentP;            // parent hit point (refraction weight needs the distance)
+};
+
+DEVI bool load_entry( const DevScene &S, const Work &W, int slot, uint32_t e, uint32_t count, RayEntry &re )
+{
+	if ( slot == 0 )
+	{
+		int x, yl, yg;
+		if ( !slot0_pixel( S, W, e, x, yl, yg ) )
+			return false;
+		re.ray = primary_ray( S, x, yg );
+		re.pix = (uint32_t) yl * (uint32_t) S.w + (uint32_t) x;
+		re.parent = -1;
+		re.type = 1;
+		re.coef = F3( 0.0f, 0.0f, 0.0f );
+		re.parentP = F3( 0.0f, 0.0f, 0.0f );
+		return true;
+	}
+	if ( e >= count )
+		return false;
+	size_t o = (size_t) ( slot - 1 ) * W.npix + e;
+	float4 a = W.rayA[o], b = W.rayB[o], c = W.rayC[o], d = W.rayD[o];
+	re.ray.src = F3( a.x, a.y, a.z );
+	re.ray.dest = F3( b.x, b.y, b.z );
+	re.ray.inv = rcp3( re.ray.dest );
+	re.pix = __float_as_uint( a.w );
+	uint32_t pk = __float_as_uint( b.w );
+	re.parent = (int) ( pk & 0xffu );
+	re.type = (int) ( ( pk >> 8 ) & 1u );
+	re.coef = F3( c.x, c.y, c.z );
+	re.parentP = F3( d.x, d.y, d.z );
+	return true;
+}
+
+// weight with which this slot's colour is folded into its parent
+// (CL/rt_funcs_primitives.cl:693-720); P is this slot's hit point
+DEVI f3 fold_weight( const RayEntry &re, f3 P )
+{
+	if ( re.type == 1 )
+		return re.coef;
+	float dist = len3( sub3( re.parentP, P ) );
+	return F3( expf( re.coef.x * -dist ), expf( re.coef.y * -dist ), expf( re.coef.z * -dist ) );
+}
+
+DEVI void flush_tally( const Work &W, const Tally &tl )
+{
+	atomicAdd( &W.ctr->nodeVisits, (unsigned long long) tl.nodes );
+	atomicAdd( &W.ctr->triTests, (unsigned long long) tl.tris );
+	atomicAdd( &W.ctr->spillPushes, (unsigned long long) tl.spills );
+	atomicMax( &W.ctr->maxStack, (unsigned long long) tl.maxSp );
+}
+
+// ---------------------------------------------------------------------------
+// k_closest: closest-hit pass of one slot
+// ---------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int slot, int wantIds )
+{
+	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
+	StackRef st;
+	st.lds = s_stack + threadIdx.x;
+	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
+	st.stride = W.spillStride;
+	Tally tl = { 0u, 0u, 0u, 0u };
+
+	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
+
+	for ( ;; )
+	{
+		uint32_t chunk = 0;
+		if ( lane_id() == 0u )
+			chunk = atomicAdd( &W.ctr->headClosest[slot], 1u );
+		chunk = wave_bcast( chunk );
+		if ( (unsigned long long) chunk * 64ull >= count )
+			break;
+		uint32_t e = chunk * 64u + lane_id();
+
+		RayEntry re;
+		bool valid = load_entry( S, W, slot, e, count, re );
+
+		float prMinT = INFINITY, trMinT = INFINITY, trU = 0.0f, trV = 0.0f;
+		uint32_t prN = 0u, trN = 0u;
+		int prB = 0, trB = 0;
+
+		if ( valid )
+		{
+			// all spheres, CL/rt_funcs_primitives.cl:381-416
+			for ( int i = 0; i < S.nSpheres; ++i )
+			{
+				float t;
+				int b = ray_sphere( re.ray, S.spheres[i], t );
+				if ( b && t < prMinT )
+				{
+					prMinT = t;
+					prN = (uint32_t) i;
+					prB = b;
+				}
+			}
+			kd_nearest<STATS>( S, re.ray, st, trMinT, trU, trV, trN, trB, tl );
+		}
+
+		// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
+		// "flag set, no valid distance, no sphere" is shaded as a miss
+		bool triHit = valid && ( trB || prB ) && ( trMinT < prMinT );
+		bool sphHit = valid && ( trB || prB ) && !( trMinT < prMinT ) && prB;
+		bool hit = triHit || sphHit;
+
+		uint32_t hidx = wave_append( &W.ctr->hitCount[slot], hit );
+		if ( hit )
+		{
+			W.hitA[hidx] = make_float4( __uint_as_float( e ), triHit ? trMinT : prMinT, trU, trV );
+			W.hitB[hidx] = make_uint2( triHit ? trN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? trB : prB ) );
+		}
+		else if ( valid )
+		{
+			size_t o = (size_t) slot * W.npix + re.pix;
+			W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( re.parent ) );
+			if ( slot == 0 )
+				W.stackPos[re.pix] = 0u;
+			else
+			{
+				f3 fw = fold_weight( re, F3( 0.0f, 0.0f, 0.0f ) );
+				W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
+			}
+		}
+		if ( slot == 0 && wantIds && valid )
+			W.hitId[re.pix] = triHit ? (int32_t) trN : ( sphHit ? -2 - (int32_t) prN : -1 );
+	}
+	if ( STATS )
+		flush_tally( W, tl );
+}
+
+// ---------------------------------------------------------------------------
+// k_shade: lighting of the compacted hits of one slot + child ray generation
+// ---------------------------------------------------------------------------
+
+// CL/rt_funcs_primitives.cl:450-564
+template <bool STATS>
+DEVI f3 light_point( const DevScene &S, const StackRef &st, f3 P, f3 N, const rt_material &mat, f3 viewer, Tally &tl )
+{
+	f3 col = F3( 0.0f, 0.0f, 0.0f );
+	for ( int o = 0; o < S.nLights; ++o )
+	{
+		float4 lc = S.lights[3 * o], lp = S.lights[3 * o + 1], lr = S.lights[3 * o + 2];
+		f3 lcol = F3( lc.z, lc.y, lc.x );          // stored b,g,r,a
+		float rad = lr.x;
+
+		f3 toLight = sub3( F3( lp.x, lp.y, lp.z ), P );
+		float d = len3( toLight );
+		toLight = div3( toLight, d );
+
+		// shadow ray :481-504; `a` keeps the sphere sum when the ray misses the scene box
+		Ray sh;
+		sh.dest = toLight;
+		sh.src = add3( P, mul3( toLight, EPSILON ) );
+		sh.inv = rcp3( toLight );
+		float a = 0.0f;
+		for ( int i = 0; i < S.nSpheres; ++i )
+		{
+			float t;
+			int b = ray_sphere( sh, S.spheres[i], t );
+			if ( b && t < d )
+				a += S.mats[S.sphereMat[i]].color.a;
+		}
+		float shadowed = clampf( a, 0.0f, 1.0f );
+		kd_alpha<STATS>( S, sh, st, d, a, tl );
+		shadowed += clampf( a, 0.0f, 1.0f );
+		shadowed *= mat.color.a;
+
+		f3 ambient = col_mult( lcol, rgb_of( mat.ambient ) );
+
+		float ang = cl_max( 0.0f, dot3( N, toLight ) );
+		f3 diffuse = col_mult( lcol, rgb_of( mat.diffuse ) );
+		diffuse = col_mult( diffuse, rgb_of( mat.color ) );
+		diffuse = col_scale( diffuse, ang * rad / d );
+
+		toLight = mul3( toLight, -1.0f );
+		toLight = reflect3( toLight, N );
+		f3 toEye = norm3( sub3( viewer, P ) );
+		ang = dot3( toEye, toLight );
+		float specFact = powf( cl_max( ang, 0.0f ), mat.specular.a );
+		f3 specular = col_mult( rgb_of( mat.specular ), lcol );
+		specular = col_scale( specular, specFact * rad / d );
+
+		diffuse = col_add( ambient, diffuse );
+		f3 tmp = col_add( diffuse, specular );
+		tmp = col_scale( tmp, 1.0f - shadowed );
+		col = col_add( tmp, col );
+	}
+	return col;
+}
+
+DEVI void push_ray( const Work &W, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
+{
+	// lanes of one wave may target different slots: aggregate per slot
+	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
+	{
+		bool mine = want && target == s;
+		if ( __ballot( mine ) == 0ull )
+			continue;
+		uint32_t idx = wave_append( &W.ctr->rayCount[s], mine );
+		if ( mine )
+		{
+			size_t o = (size_t) ( s - 1 ) * W.npix + idx;
+			W.rayA[o] = make_float4( r.src.x, r.src.y, r.src.z, __uint_as_float( pix ) );
+			W.rayB[o] = make_float4( r.dest.x, r.dest.y, r.dest.z,
+				__uint_as_float( (uint32_t) parent | ( (uint32_t) type << 8 ) ) );
+			W.rayC[o] = make_float4( coef.x, coef.y, coef.z, 0.0f );
+			W.rayD[o] = make_float4( P.x, P.y, P.z, 0.0f );
+		}
+	}
+}
+
+template <bool STATS>
+__global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int slot )
+{
+	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
+	StackRef st;
+	st.lds = s_stack + threadIdx.x;
+	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
+	st.stride = W.spillStride;
+	Tally tl = { 0u, 0u, 0u, 0u };
+
+	const uint32_t count = W.ctr->hitCount[slot];
+	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
+
+	for ( ;; )
+	{
+		uint32_t chunk = 0;
+		if ( lane_id() == 0u )
+			chunk = atomicAdd( &W.ctr->headShade[slot], 1u );
+		chunk = wave_bcast( chunk );
+		if ( (unsigned long long) chunk * 64ull >= count )
+			break;
+		uint32_t h = chunk * 64u + lane_id();
+		bool valid = h < count;
+
+		RayEntry re;
+		re.pix = 0u;
+		float4 ha = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+		uint2 hb = make_uint2( 0u, 0u );
+		if ( valid )
+		{
+			ha = W.hitA[h];
+			hb = W.hitB[h];
+			valid = load_entry( S, W, slot, __float_as_uint( ha.x ), rayCount, re );
+		}
+
+		bool pushRefl = false, pushRefr = false;
+		Ray rRefl, rRefr;
+		f3 P = F3( 0.0f, 0.0f, 0.0f ), cRefl = P, cRefr = P;
+		int sp = 0;
+
+		if ( valid )
+		{
+			f3 N;
+			uint32_t matIdx;
+			int bNearest = (int) hb.y;
+			float t = ha.y;
+
+			if ( hb.x & 0x80000000u )
+			{
+				// sphere hit point and normal, CL/rt_funcs_primitives.cl:31-49
+				uint32_t si = hb.x & 0x7fffffffu;
+				float4 s = S.spheres[si];
+				matIdx = S.sphereMat[si];
+				P = mul3( re.ray.dest, t );
+				P = add3( P, re.ray.src );
+				N = div3( sub3( P, F3( s.x, s.y, s.z ) ), s.w );
+				N = mul3( N, (float) bNearest );
+			}
+			else
+			{
+				// triangle hit point, barycentric normal (not normalised), :62-72
+				const float4 *sp4 = S.shade + 3u * (size_t) hb.x;
+				float4 a = sp4[0], b = sp4[1], c = sp4[2];
+				f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
+				float u = ha.z, v = ha.w;
+				matIdx = __float_as_uint( c.y );
+				P = add3( mul3( re.ray.dest, t ), re.ray.src );
+				N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
+			}
+
+			rt_material mat = S.mats[matIdx];
+			f3 col = light_point<STATS>( S, st, P, N, mat, re.ray.src, tl );
+
+			sp = slot == 0 ? 0 : (int) W.stackPos[re.pix];
+
+			// reflection ray :643-655
+			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 )
+				&& ( ( mat.reflect.r + mat.reflect.g + mat.reflect.b ) > 0.0f ) )
+			{
+				++sp;
+				pushRefl = true;
+				rRefl.dest = reflect3( re.ray.dest, N );
+				rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
+				cRefl = rgb_of( mat.reflect );
+			}
+			// refraction ray :657-677
+			if ( ( ( sp + 1 ) < S.stackSize ) && ( mat.color.a < 0.99f ) )
+			{
+				float nRel = ENV_OPT_DENSITY / mat.optDens;
+				float cosI = dot3( N, re.ray.dest );
+				float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
+				if ( sinT < 1.0f )
+				{
+					++sp;
+					pushRefr = true;
+					rRefr.dest = norm3( sub3( mul3( re.ray.dest, nRel ),
+						mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
+					rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
+					cRefr = F3( mat.color.r * mat.lightFalloff, mat.color.g * mat.lightFalloff,
+						mat.color.b * mat.lightFalloff );
+				}
+			}
+
+			size_t o = (size_t) slot * W.npix + re.pix;
+			W.res[o] = make_float4( col.x, col.y, col.z, __int_as_float( re.parent ) );
+			if ( slot > 0 )
+			{
+				f3 fw = fold_weight( re, P );
+				W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
+			}
+			if ( slot == 0 || pushRefl || pushRefr )
+				W.stackPos[re.pix] = (uint32_t) sp;
+		}
+
+		// slot numbers: reflection takes the first new slot, refraction the next
+		int reflSlot = sp - ( pushRefr ? 1 : 0 );
+		push_ray( W, reflSlot, pushRefl, rRefl, re.pix, slot, 1, cRefl, P );
+		push_ray( W, sp, pushRefr, rRefr, re.pix, slot, 0, cRefr, P );
+	}
+	if ( STATS )
+		flush_tally( W, tl );
+}
+
+// ---------------------------------------------------------------------------
+// k_fold: children into parents, last slot first (CL/rt_funcs_primitives.cl:688-725),
+// then the truncating 8-bit store (CL/rt_raytrace.cl:83-86)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__( RT_BLOCK ) void k_fold( Work W, rt_argb *out, int stackSize )
+{
+	uint32_t p = blockIdx.x * RT_BLOCK + threadIdx.x;
+	if ( p >= W.npix )
+		return;
+	int n = (int) W.stackPos[p] + 1;
+	f3 col[RT_MAX_SLOTS];
+	f3 fw[RT_MAX_SLOTS];
+	int par[RT_MAX_SLOTS];
+#pragma unroll
+	for ( int s = 0; s < RT_MAX_SLOTS; ++s )
+	{
+		col[s] = fw[s] = F3( 0.0f, 0.0f, 0.0f );
+		par[s] = -1;
+		if ( s < n && s < stackSize )
+		{
+			float4 r = W.res[(size_t) s * W.npix + p];
+			col[s] = F3( r.x, r.y, r.z );
+			par[s] = __float_as_int( r.w );
+			if ( s > 0 )
+			{
+				float4 f = W.fac[(size_t) s * W.npix + p];
+				fw[s] = F3( f.x, f.y, f.z );
+			}
+		}
+	}
+#pragma unroll
+	for ( int c = RT_MAX_SLOTS - 1; c >= 1; --c )
+	{
+		if ( c < n )
+		{
+			f3 add = F3( col[c].x * fw[c].x, col[c].y * fw[c].y, col[c].z * fw[c].z );
+#pragma unroll
+			for ( int q = 0; q < c; ++q )
+				if ( par[c] == q )
+					col[q] = clamp01( add3( col[q], add ) );
+		}
+	}
+	rt_argb px;
+	px.a = (unsigned char) ( 255.0f * 0.0f );
+	px.r = (unsigned char) ( 255.0f * col[0].x );
+	px.g = (unsigned char) ( 255.0f * col[0].y );
+	px.b = (unsigned char) ( 255.0f * col[0].z );
+	out[p] = px;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+static int fail( const char *fmt, ... )
+{
+	va_list ap;
+	va_start( ap, fmt );
+	vsnprintf( g_err, sizeof( g_err ), fmt, ap );
+	va_end( ap );
+	return 1;
+}
+
+#define HIPCHK( x ) do { hipError_t e_ = ( x ); if ( e_ != hipSuccess ) \
+	return fail( "%s failed: %s (%s:%d)", #x, hipGetErrorString( e_ ), __FILE__, __LINE__ ); } while ( 0 )
+
+struct DevBuf
+{
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct rt_hip_ctx
+{
+	int device = 0;
+	int numCU = 0;
+	hipStream_t own = nullptr, stream = nullptr;
+	DevScene S;
+	Work W;
+	DevBuf nodes, recs, shade, mats, spheres, sphereMat, lights;
+	DevBuf ctr, rays, hitA, hitB, res, fac, stackPos, hitId, spill, frame;
+	uint64_t nNodes = 0, nRecs = 0, nTris = 0, nMats = 0;
+	uint64_t maxMatTree = 0, maxMatSphere = 0;   // highest material slot referenced
+	int treeDepth = 0;
+	int allocStack = 0;           // stack size the work buffers were sized for
+	bool workDirty = true;
+	int gridClosest[2] = { 0, 0 }, gridShade[2] = { 0, 0 };
+	int maxGrid = 0;
+	hipEvent_t ev[2 * RT_MAX_SLOTS + 3] = {};
+	bool haveEvents = false, timed = false;
+	int timedSlots = 0;
+	uint32_t validPixels = 0;
+};
+
+const char *rt_hip_last_error( void ) { return g_err; }
+
+int rt_hip_device_count( void )
+{
+	int n = 0;
+	if ( hipGetDeviceCount( &n ) != hipSuccess )
+		return 0;
+	return n;
+}
+
+static int ensure( rt_hip_ctx *c, DevBuf &b, size_t bytes )
+{
+	if ( bytes == 0 ) bytes = 256;
+	if ( b.cap >= bytes )
+		return 0;
+	if ( b.p )
+	{
+		HIPCHK( hipStreamSynchronize( c->stream ) );
+		HIPCHK( hipFree( b.p ) );
+		b.p = nullptr;
+		b.cap = 0;
+	}
+	HIPCHK( hipMalloc( &b.p, bytes ) );
+	b.cap = bytes;
+	return 0;
+}
+
+static int upload( rt_hip_ctx *c, DevBuf &b, const void *src, size_t bytes )
+{
+	if ( ensure( c, b, bytes ) )
+		return 1;
+	if ( bytes )
+	{
+		// pageable source: the copy is staged before the call returns
+		HIPCHK( hipMemcpyAsync( b.p, src, bytes, hipMemcpyHostToDevice, c->stream ) );
+		HIPCHK( hipStreamSynchronize( c->stream ) );
+	}
+	return 0;
+}
+
+rt_hip_ctx *rt_hip_create( int device )
+{
+	int n = rt_hip_device_count();
+	if ( device < 0 || device >= n )
+	{
+		fail( "rt_hip_create: device %d not available (%d HIP devices)", device, n );
+		return nullptr;
+	}
+	if ( hipSetDevice( device ) != hipSuccess )
+	{
+		fail( "hipSetDevice(%d) failed", device );
+		return nullptr;
+	}
+	rt_hip_ctx *c = new rt_hip_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	if ( hipGetDeviceProperties( &prop, device ) != hipSuccess || hipStreamCreate( &c->own ) != hipSuccess )
+	{
+		fail( "rt_hip_create: device query / stream creation failed" );
+		delete c;
+		return nullptr;
+	}
+	c->numCU = prop.multiProcessorCount;
+	c->stream = c->own;
+	memset( &c->S, 0, sizeof( c->S ) );
+	memset( &c->W, 0, sizeof( c->W ) );
+	c->S.stackSize = STACK_SIZE;
+	c->S.bandH = 16;
+	c->S.nParts = 1;
+	c->S.part = 0;
+	for ( int i = 0; i < 16; ++i )
+		c->S.world[i] = c->S.vtp[i] = ( i % 5 == 0 ) ? 1.0f : 0.0f;
+
+	// persistent grids: one resident wave set per CU, as many blocks as fit
+	int occ = 0;
+	struct { const void *f; int *dst; } ks[4] = {
+		{ (const void *) k_closest<false>, &c->gridClosest[0] }, { (const void *) k_closest<true>, &c->gridClosest[1] },
+		{ (const void *) k_shade<false>, &c->gridShade[0] }, { (const void *) k_shade<true>, &c->gridShade[1] } };
+	for ( auto &k : ks )
+	{
+		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
+			occ = 1;
+		if ( occ > 8 ) occ = 8;
+		*k.dst = occ * c->numCU;
+		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
+	}
+	return c;
+}
+
+void rt_hip_destroy( rt_hip_ctx *c )
+{
+	if ( !c )
+		return;
+	(void) hipSetDevice( c->device );
+	(void) hipStreamSynchronize( c->stream );
+	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights,
+		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->res, &c->fac, &c->stackPos, &c->hitId, &c->spill, &c->frame };
+	for ( DevBuf *b : all )
+		if ( b->p ) (void) hipFree( b->p );
+	if ( c->haveEvents )
+		for ( auto &e : c->ev ) (void) hipEventDestroy( e );
+	if ( c->own ) (void) hipStreamDestroy( c->own );
+	delete c;
+}
+
+int rt_hip_set_stream( rt_hip_ctx *c, void *s )
+{
+	if ( !c ) return fail( "null context" );
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	c->stream = s ? (hipStream_t) s : c->own;
+	return 0;
+}
+
+int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes, const rt_hip_trirec *recs,
+	uint64_t nRecs, const rt_hip_trishade *shade, uint64_t nTris, const rt_box *bbox, int depth )
+{
+	if ( !c || !nodes || !bbox || nNodes == 0 ) return fail( "rt_hip_upload_tree: bad arguments" );
+	if ( depth > RT_HIP_MAX_TREE_DEPTH )
+		return fail( "rt_hip_upload_tree: tree depth %d exceeds the traversal stack (%d)", depth, RT_HIP_MAX_TREE_DEPTH );
+	if ( nNodes >= ( 1ull << 30 ) || nRecs >= ( 1ull << 30 ) || nTris >= ( 1ull << 31 ) )
+		return fail( "rt_hip_upload_tree: tree too large for 32-bit node links" );
+	// host-side shape check: every link and record range must stay inside the
+	// arrays (an out-of-range link would fault the GPU), and children must
+	// come after their parent so no traversal can loop
+	for ( uint64_t i = 0; i < nNodes; ++i )
+	{
+		uint32_t b = nodes[i].b;
+		if ( ( b & 3u ) == 3u )
+		{
+			if ( (uint64_t) nodes[i].a + ( b >> 2 ) > nRecs )
+				return fail( "rt_hip_upload_tree: leaf %llu references records beyond %llu", (unsigned long long) i, (unsigned long long) nRecs );
+		}
+		else if ( ( b >> 2 ) >= nNodes || ( b >> 2 ) <= i || i + 1 >= nNodes )
+			return fail( "rt_hip_upload_tree: node %llu has an invalid child link", (unsigned long long) i );
+	}
+	uint64_t maxMat = 0;
+	for ( uint64_t i = 0; i < nRecs; ++i )
+	{
+		if ( recs[i].tri >= nTris )
+			return fail( "rt_hip_upload_tree: record %llu references triangle %u of %llu", (unsigned long long) i, recs[i].tri, (unsigned long long) nTris );
+		if ( recs[i].mat > maxMat ) maxMat = recs[i].mat;
+	}
+	for ( uint64_t i = 0; i < nTris; ++i )
+		if ( shade[i].mat > maxMat ) maxMat = shade[i].mat;
+	c->maxMatTree = maxMat;
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( upload( c, c->nodes, nodes, nNodes * sizeof( rt_hip_kdnode ) ) ) return 1;
+	if ( upload( c, c->recs, recs, nRecs * sizeof( rt_hip_trirec ) ) ) return 1;
+	if ( upload( c, c->shade, shade, nTris * sizeof( rt_hip_trishade ) ) ) return 1;
+	c->nNodes = nNodes; c->nRecs = nRecs; c->nTris = nTris; c->treeDepth = depth;
+	c->S.nodes = (const uint2 *) c->nodes.p;
+	c->S.recs = (const float4 *) c->recs.p;
+	c->S.shade = (const float4 *) c->shade.p;
+	c->S.bbC[0] = bbox->center.x; c->S.bbC[1] = bbox->center.y; c->S.bbC[2] = bbox->center.z;
+	c->S.bbE[0] = bbox->extents.x; c->S.bbE[1] = bbox->extents.y; c->S.bbE[2] = bbox->extents.z;
+	return 0;
+}
+
+int rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n )
+{
+	if ( !c || ( n && !m ) ) return fail( "rt_hip_upload_materials: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( upload( c, c->mats, m, n * sizeof( rt_material ) ) ) return 1;
+	c->nMats = n;
+	c->S.mats = (const rt_material *) c->mats.p;
+	return 0;
+}
+
+int rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n )
+{
+	if ( !c || ( n && !s ) ) return fail( "rt_hip_upload_spheres: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	std::vector<float> g( 4 * n + 4 );
+	std::vector<uint32_t> mi( n + 1 );
+	c->maxMatSphere = 0;
+	for ( uint64_t i = 0; i < n; ++i )
+	{
+		if ( s[i].mat >= ( 1ull << 31 ) ) return fail( "rt_hip_upload_spheres: material slot out of range" );
+		if ( s[i].mat > c->maxMatSphere ) c->maxMatSphere = s[i].mat;
+		g[4 * i] = s[i].pos.x; g[4 * i + 1] = s[i].pos.y; g[4 * i + 2] = s[i].pos.z; g[4 * i + 3] = s[i].rad;
+		mi[i] = (uint32_t) s[i].mat;
+	}
+	if ( upload( c, c->spheres, g.data(), 16 * n ) ) return 1;
+	if ( upload( c, c->sphereMat, mi.data(), 4 * n ) ) return 1;
+	c->S.spheres = (const float4 *) c->spheres.p;
+	c->S.sphereMat = (const uint32_t *) c->sphereMat.p;
+	c->S.nSpheres = (int) n;
+	return 0;
+}
+
+int rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n )
+{
+	if ( !c || ( n && !l ) ) return fail( "rt_hip_upload_lights: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	std::vector<float> g( 12 * n + 12, 0.0f );
+	for ( uint64_t i = 0; i < n; ++i )
+	{
+		float *p = g.data() + 12 * i;
+		p[0] = l[i].col.b; p[1] = l[i].col.g; p[2] = l[i].col.r; p[3] = l[i].col.a;
+		p[4] = l[i].pos.x; p[5] = l[i].pos.y; p[6] = l[i].pos.z;
+		p[8] = l[i].rad;
+	}
+	if ( upload( c, c->lights, g.data(), 48 * n ) ) return 1;
+	c->S.lights = (const float4 *) c->lights.p;
+	c->S.nLights = (int) n;
+	return 0;
+}
+
+int rt_hip_set_camera( rt_hip_ctx *c, const rt_camera *cam )
+{
+	if ( !c || !cam ) return fail( "rt_hip_set_camera: bad arguments" );
+	memcpy( c->S.world, &cam->world, 64 );
+	memcpy( c->S.vtp, &cam->viewToPersp, 64 );
+	return 0;
+}
+
+static void update_local_rows( rt_hip_ctx *c )
+{
+	DevScene &S = c->S;
+	int rows = 0;
+	if ( S.h > 0 )
+	{
+		int bands = ( S.h + S.bandH - 1 ) / S.bandH;
+		for ( int b = S.part; b < bands; b += S.nParts )
+		{
+			int r = S.h - b * S.bandH;
+			rows += r < S.bandH ? r : S.bandH;
+		}
+	}
+	// compact storage keeps full bands except possibly the last one; a short
+	// last band can only be the final local band, so rows == local extent
+	S.localH = rows;
+	c->workDirty = true;
+}
+
+int rt_hip_set_image( rt_hip_ctx *c, int w, int h )
+{
+	if ( !c || w < 2 || h < 2 || (long long) w * h >= ( 1ll << 30 ) ) return fail( "rt_hip_set_image: bad size %dx%d", w, h );
+	c->S.w = w;
+	c->S.h = h;
+	update_local_rows( c );
+	return 0;
+}
+
+int rt_hip_set_tile( rt_hip_ctx *c, int bandH, int nParts, int part )
+{
+	if ( !c || bandH < 1 || nParts < 1 || part < 0 || part >= nParts ) return fail( "rt_hip_set_tile: bad arguments" );
+	c->S.bandH = bandH;
+	c->S.nParts = nParts;
+	c->S.part = part;
+	update_local_rows( c );
+	return 0;
+}
+
+int rt_hip_local_rows( rt_hip_ctx *c ) { return c ? c->S.localH : 0; }
+
+int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
+{
+	if ( !c ) return fail( "null context" );
+	if ( key == RT_PARAM_STACK_SIZE )
+	{
+		if ( value < 1 || value > RT_STACK_SIZE_MAX ) return fail( "RT_PARAM_STACK_SIZE must be 1..%d", RT_STACK_SIZE_MAX );
+		c->S.stackSize = value;
+		c->workDirty = true;
+		return 0;
+	}
+	return fail( "rt_hip_set_param: unknown key %d", key );
+}
+
+static int prepare_work( rt_hip_ctx *c )
+{
+	DevScene &S = c->S;
+	Work &W = c->W;
+	if ( S.w < 2 || S.h < 2 ) return fail( "image size not set" );
+	size_t npix = (size_t) S.w * (size_t) S.localH;
+	if ( npix == 0 ) npix = 1;
+	int slots = S.stackSize;
+	if ( ensure( c, c->ctr, sizeof( Counters ) ) ) return 1;
+	if ( ensure( c, c->rays, 4 * sizeof( float4 ) * npix * (size_t) ( slots > 1 ? slots - 1 : 1 ) ) ) return 1;
+	if ( ensure( c, c->hitA, sizeof( float4 ) * npix ) ) return 1;
+	if ( ensure( c, c->hitB, sizeof( uint2 ) * npix ) ) return 1;
+	if ( ensure( c, c->res, sizeof( float4 ) * npix * slots ) ) return 1;
+	if ( ensure( c, c->fac, sizeof( float4 ) * npix * slots ) ) return 1;
+	if ( ensure( c, c->stackPos, sizeof( uint32_t ) * npix ) ) return 1;
+	if ( ensure( c, c->hitId, sizeof( int32_t ) * npix ) ) return 1;
+	if ( ensure( c, c->frame, sizeof( rt_argb ) * npix ) ) return 1;
+	if ( ensure( c, c->spill, sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
+	size_t per = npix * (size_t) ( slots > 1 ? slots - 1 : 1 );
+	W.ctr = (Counters *) c->ctr.p;
+	W.rayA = (float4 *) c->rays.p;
+	W.rayB = W.rayA + per;
+	W.rayC = W.rayB + per;
+	W.rayD = W.rayC + per;
+	W.hitA = (float4 *) c->hitA.p;
+	W.hitB = (uint2 *) c->hitB.p;
+	W.res = (float4 *) c->res.p;
+	W.fac = (float4 *) c->fac.p;
+	W.stackPos = (uint32_t *) c->stackPos.p;
+	W.hitId = (int32_t *) c->hitId.p;
+	W.spill = (uint2 *) c->spill.p;
+	W.npix = (uint32_t) ( (size_t) S.w * (size_t) S.localH );
+	W.tilesX = (uint32_t) ( ( S.w + 7 ) / 8 );
+	W.nChunks0 = W.tilesX * (uint32_t) ( ( S.localH + 7 ) / 8 );
+	W.spillStride = (uint32_t) c->maxGrid * RT_BLOCK;
+	c->validPixels = W.npix;
+	c->workDirty = false;
+	return 0;
+}
+
+int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
+{
+	if ( !c ) return fail( "null context" );
+	if ( !c->S.nodes ) return fail( "rt_hip_render: no tree uploaded" );
+	if ( !c->S.mats ) return fail( "rt_hip_render: no materials uploaded" );
+	// a material slot beyond the uploaded table would be an out-of-bounds read on the GPU
+	if ( ( c->nRecs && c->maxMatTree >= c->nMats ) || ( c->S.nSpheres && c->maxMatSphere >= c->nMats ) )
+		return fail( "rt_hip_render: geometry references material slot %llu but only %llu are uploaded",
+			(unsigned long long) ( c->maxMatTree > c->maxMatSphere ? c->maxMatTree : c->maxMatSphere ), (unsigned long long) c->nMats );
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( c->S.nSpheres == 0 && !c->S.spheres ) { rt_sphere z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_spheres( c, &z, 0 ) ) return 1; }
+	if ( c->S.nLights == 0 && !c->S.lights ) { rt_point_light z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_lights( c, &z, 0 ) ) return 1; }
+	if ( c->workDirty && prepare_work( c ) ) return 1;
+	const bool stats = flags & RT_HIP_STATS, ids = flags & RT_HIP_HITIDS, timing = flags & RT_HIP_TIMING;
+	const DevScene &S = c->S;
+	const Work &W = c->W;
+	rt_argb *out = d_out ? (rt_argb *) d_out : (rt_argb *) c->frame.p;
+	hipStream_t s = c->stream;
+
+	if ( timing && !c->haveEvents )
+	{
+		for ( auto &e : c->ev ) HIPCHK( hipEventCreate( &e ) );
+		c->haveEvents = true;
+	}
+	c->timed = timing;
+	c->timedSlots = S.stackSize;
+	int evi = 0;
+
+	HIPCHK( hipMemsetAsync( c->ctr.p, 0, sizeof( Counters ), s ) );
+	if ( W.npix == 0 )
+		return 0;
+	for ( int k = 0; k < S.stackSize; ++k )
+	{
+		// a persistent grid never needs more waves than there are chunks
+		uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
+		int gc = c->gridClosest[stats], gs = c->gridShade[stats];
+		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
+		if ( k == 0 && want < (uint32_t) gs ) gs = (int) ( want ? want : 1u );
+		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+		if ( stats ) hipLaunchKernelGGL( k_closest<true>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
+		else hipLaunchKernelGGL( k_closest<false>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
+		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+		if ( stats ) hipLaunchKernelGGL( k_shade<true>, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
+		else hipLaunchKernelGGL( k_shade<false>, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
+	}
+	if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+	hipLaunchKernelGGL( k_fold, dim3( ( W.npix + RT_BLOCK - 1 ) / RT_BLOCK ), dim3( RT_BLOCK ), 0, s, W, out, S.stackSize );
+	if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+	HIPCHK( hipGetLastError() );
+	return 0;
+}
+
+int rt_hip_sync( rt_hip_ctx *c )
+{
+	if ( !c ) return fail( "null context" );
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host )
+{
+	if ( !c || !host ) return fail( "rt_hip_read_frame: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( !c->frame.p ) return fail( "rt_hip_read_frame: nothing rendered" );
+	HIPCHK( hipMemcpyAsync( host, c->frame.p, sizeof( rt_argb ) * (size_t) c->W.npix, hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host )
+{
+	if ( !c || !host ) return fail( "rt_hip_read_hit_ids: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( !c->hitId.p ) return fail( "rt_hip_read_hit_ids: nothing rendered" );
+	HIPCHK( hipMemcpyAsync( host, c->hitId.p, sizeof( int32_t ) * (size_t) c->W.npix, hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
+{
+	if ( !c || !out ) return fail( "rt_hip_get_stats: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( !c->ctr.p ) return fail( "rt_hip_get_stats: nothing rendered" );
+	Counters h;
+	HIPCHK( hipMemcpyAsync( &h, c->ctr.p, sizeof( h ), hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	memset( out, 0, sizeof( *out ) );
+	out->raysClosest = c->validPixels;
+	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.rayCount[k];
+	for ( int k = 0; k < RT_MAX_SLOTS; ++k ) out->hits += h.hitCount[k];
+	out->raysShadow = out->hits * (uint64_t) c->S.nLights;
+	out->nodeVisits = h.nodeVisits;
+	out->triTests = h.triTests;
+	out->spillPushes = h.spillPushes;
+	out->maxStack = h.maxStack;
+	return 0;
+}
+
+int rt_hip_kernel_times( rt_hip_ctx *c, float ms[4], int launches[4] )
+{
+	if ( !c || !ms || !launches ) return fail( "rt_hip_kernel_times: bad arguments" );
+	if ( !c->timed ) return fail( "rt_hip_kernel_times: last render was not timed" );
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	ms[0] = ms[1] = ms[2] = ms[3] = 0.0f;
+	int n = c->timedSlots, e = 0;
+	for ( int k = 0; k < n; ++k )
+	{
+		float a = 0.0f, b = 0.0f;
+		HIPCHK( hipEventElapsedTime( &a, c->ev[e], c->ev[e + 1] ) );
+		HIPCHK( hipEventElapsedTime( &b, c->ev[e + 1], c->ev[e + 2] ) );
+		ms[0] += a;
+		ms[1] += b;
+		e += 2;
+	}
+	HIPCHK( hipEventElapsedTime( &ms[2], c->ev[e], c->ev[e + 1] ) );
+	HIPCHK( hipEventElapsedTime( &ms[3], c->ev[0], c->ev[e + 1] ) );
+	launches[0] = launches[1] = n;
+	launches[2] = 1;
+	launches[3] = 2 * n + 1;
+	return 0;
+}

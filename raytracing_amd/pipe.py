@@ -1,0 +1,311 @@
+"""Python mirror of the C API (ctypes over librt_amd.so).
+
+RenderPipe  - the reference's rt_render_pipe_* call sequence (create, add
+              materials / lights / spheres / meshes, set camera, draw).
+HipRenderer - the rt_hip_* layer underneath for callers that keep a scene
+              resident in HBM (benchmark, multi-GPU driver, parity tests).
+FlatTree    - the host kd builder's output in the HBM layout.
+
+Every call goes to the native library; nothing here computes pixels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import types as T
+from ._lib import FlatTree as _FlatTreeStruct
+from ._lib import RenderPipeStruct, RtError, Stats, check, lib
+
+RT_HIP_STATS, RT_HIP_HITIDS, RT_HIP_TIMING = 1, 2, 4
+(RT_PARAM_STACK_SIZE, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
+ RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE) = 1, 2, 3, 4, 5
+
+kdnode = np.dtype([("a", "<u4"), ("b", "<u4")])
+trirec = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3),
+                   ("tri", "<u4"), ("mat", "<u4"), ("_pad", "<u4")])
+trishade = np.dtype([("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
+                     ("mat", "<u4"), ("_pad", "<u4", 2)])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _view(ptr, count, dtype):
+    if not ptr or count == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class FlatTree:
+    """kd-tree in the HBM layout (rt_kdtree_flat).  Arrays are views into
+    memory owned by the native library until release()."""
+
+    def __init__(self, struct):
+        self._s = struct
+        self.nodes = _view(struct.nodes, struct.nNodes, kdnode)
+        self.recs = _view(struct.recs, struct.nRecs, trirec)
+        self.shade = _view(struct.shade, struct.nTris, trishade)
+        self.bbox = np.frombuffer(bytes(struct.bbox), T.box)[0]
+        self.depth = struct.depth
+
+    @classmethod
+    def build(cls, verts, tris, max_depth=10, max_prims=7, threads=0):
+        verts = np.ascontiguousarray(verts, T.vertex)
+        tris = np.ascontiguousarray(tris, T.triangle)
+        s = _FlatTreeStruct()
+        rc = lib().rt_kdtree_build_flat(_p(verts), _p(tris), C.c_uint64(len(verts)),
+                                        C.c_uint64(len(tris)), C.c_int(max_depth), C.c_int(max_prims),
+                                        C.c_int(threads), C.byref(s))
+        if rc:
+            raise RtError(f"rt_kdtree_build_flat failed with code {rc}")
+        return cls(s)
+
+    @classmethod
+    def from_interchange(cls, nodes, idx, verts, tris, bbox):
+        nodes = np.ascontiguousarray(nodes, T.cl_kdtree_node)
+        idx = np.ascontiguousarray(idx, np.uint64)
+        verts = np.ascontiguousarray(verts, T.vertex)
+        tris = np.ascontiguousarray(tris, T.triangle)
+        bb = np.array([bbox], T.box)
+        s = _FlatTreeStruct()
+        rc = lib().rt_kdtree_flatten(_p(nodes), C.c_uint64(len(nodes)), _p(idx), C.c_uint64(len(idx)),
+                                     _p(verts), _p(tris), C.c_uint64(len(verts)), C.c_uint64(len(tris)),
+                                     _p(bb), C.byref(s))
+        if rc:
+            raise RtError(f"rt_kdtree_flatten failed with code {rc}")
+        return cls(s)
+
+    def expand(self):
+        """-> (nodes T.cl_kdtree_node[], idx uint64[]) in the reference's flat format."""
+        pn, pi = C.c_void_p(), C.c_void_p()
+        nn, ni = C.c_uint64(), C.c_uint64()
+        rc = lib().rt_kdtree_flat_expand(C.byref(self._s), C.byref(pn), C.byref(nn), C.byref(pi), C.byref(ni))
+        if rc:
+            raise RtError(f"rt_kdtree_flat_expand failed with code {rc}")
+        nodes = _view(pn.value, nn.value, T.cl_kdtree_node).copy()
+        idx = _view(pi.value, ni.value, np.dtype("<u8")).copy()
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(pn)
+        libc.free(pi)
+        return nodes, idx
+
+    def release(self):
+        if self._s is not None:
+            lib().rt_kdtree_flat_release(C.byref(self._s))
+            self._s = None
+            self.nodes = self.recs = self.shade = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class HipRenderer:
+    """One rt_hip_ctx: a scene resident on one GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = lib()
+        self._c = self._L.rt_hip_create(device)
+        if not self._c:
+            raise RtError("rt_hip_create: " + self._L.rt_hip_last_error().decode())
+        self._c = C.c_void_p(self._c)
+        self.w = self.h = 0
+        if stream is not None:
+            check(self._L.rt_hip_set_stream(self._c, C.c_void_p(stream)), "rt_hip_set_stream")
+
+    def close(self):
+        if self._c:
+            self._L.rt_hip_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene ----------------------------------------------------------------
+    def upload_tree(self, tree):
+        check(self._L.rt_hip_upload_tree(self._c, _p(tree.nodes), C.c_uint64(len(tree.nodes)),
+                                         _p(tree.recs), C.c_uint64(len(tree.recs)),
+                                         _p(tree.shade), C.c_uint64(len(tree.shade)),
+                                         _p(np.array([tree.bbox], T.box)), C.c_int(tree.depth)),
+              "rt_hip_upload_tree")
+
+    def upload_materials(self, mats):
+        mats = np.ascontiguousarray(mats, T.material)
+        check(self._L.rt_hip_upload_materials(self._c, _p(mats), C.c_uint64(len(mats))), "rt_hip_upload_materials")
+
+    def upload_spheres(self, sph):
+        sph = np.ascontiguousarray(sph, T.sphere)
+        keep = sph if len(sph) else np.zeros(1, T.sphere)
+        check(self._L.rt_hip_upload_spheres(self._c, _p(keep), C.c_uint64(len(sph))), "rt_hip_upload_spheres")
+
+    def upload_lights(self, lts):
+        lts = np.ascontiguousarray(lts, T.point_light)
+        keep = lts if len(lts) else np.zeros(1, T.point_light)
+        check(self._L.rt_hip_upload_lights(self._c, _p(keep), C.c_uint64(len(lts))), "rt_hip_upload_lights")
+
+    def set_camera(self, cam):
+        cam = np.array([cam], T.camera)
+        check(self._L.rt_hip_set_camera(self._c, _p(cam)), "rt_hip_set_camera")
+
+    def set_image(self, w, h):
+        check(self._L.rt_hip_set_image(self._c, C.c_int(w), C.c_int(h)), "rt_hip_set_image")
+        self.w, self.h = w, h
+
+    def set_tile(self, band_h, n_parts, part):
+        check(self._L.rt_hip_set_tile(self._c, C.c_int(band_h), C.c_int(n_parts), C.c_int(part)), "rt_hip_set_tile")
+
+    def set_param(self, key, value):
+        check(self._L.rt_hip_set_param(self._c, C.c_int(key), C.c_int(value)), "rt_hip_set_param")
+
+    @property
+    def local_rows(self):
+        return self._L.rt_hip_local_rows(self._c)
+
+    def load_scene(self, scene, tree=None, max_depth=10, max_prims=7, threads=0):
+        """Upload everything `scene` holds; builds the tree unless given. -> tree"""
+        if tree is None:
+            v, t = scene.flatten()
+            tree = FlatTree.build(v, t, max_depth, max_prims, threads)
+        self.upload_tree(tree)
+        self.upload_materials(scene.material_table())
+        self.upload_spheres(scene.sphere_table())
+        self.upload_lights(scene.light_table())
+        self.set_camera(scene.camera)
+        self.set_image(scene.w, scene.h)
+        self.set_param(RT_PARAM_STACK_SIZE, scene.stack_size)
+        return tree
+
+    # -- frame ----------------------------------------------------------------
+    def render(self, flags=0, d_out=None):
+        """Enqueue one frame (asynchronous).  d_out: device pointer (int) or None."""
+        check(self._L.rt_hip_render(self._c, C.c_void_p(d_out) if d_out else None, C.c_uint(flags)), "rt_hip_render")
+
+    def sync(self):
+        check(self._L.rt_hip_sync(self._c), "rt_hip_sync")
+
+    def read_frame(self):
+        """-> uint8 [local_rows, w, 4] in b,g,r,a order"""
+        out = np.zeros((self.local_rows, self.w, 4), np.uint8)
+        check(self._L.rt_hip_read_frame(self._c, _p(out)), "rt_hip_read_frame")
+        return out
+
+    def read_hit_ids(self):
+        out = np.zeros((self.local_rows, self.w), np.int32)
+        check(self._L.rt_hip_read_hit_ids(self._c, _p(out)), "rt_hip_read_hit_ids")
+        return out
+
+    def stats(self):
+        st = Stats()
+        check(self._L.rt_hip_get_stats(self._c, C.byref(st)), "rt_hip_get_stats")
+        return st.as_dict()
+
+    def kernel_times(self):
+        """After render(RT_HIP_TIMING): ({closest, shade, fold, frame} ms, launch counts)."""
+        ms = (C.c_float * 4)()
+        n = (C.c_int * 4)()
+        check(self._L.rt_hip_kernel_times(self._c, ms, n), "rt_hip_kernel_times")
+        names = ("closest", "shade", "fold", "frame")
+        return dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n]))
+
+
+class RenderPipe:
+    """The reference's render-pipe call sequence (rt_funcs_render_pipe.h)."""
+
+    def __init__(self, w, h, device=0):
+        self._L = lib()
+        self._rp = RenderPipeStruct()
+        self._L.rt_render_pipe_select_device(C.c_int(device))
+        self._L.rt_render_pipe_create(C.byref(self._rp), C.c_int(w), C.c_int(h))
+        self._open = True
+
+    def set_image_size(self, w, h):
+        self._L.rt_render_pipe_set_image_size(C.byref(self._rp), C.c_int(w), C.c_int(h))
+
+    def set_param(self, key, value):
+        self._L.rt_render_pipe_set_param(C.byref(self._rp), C.c_int(key), C.c_int(value))
+
+    def set_tile(self, band_h, n_parts, part):
+        self._L.rt_render_pipe_set_tile(C.byref(self._rp), C.c_int(band_h), C.c_int(n_parts), C.c_int(part))
+
+    def set_camera(self, cam):
+        cam = np.array([cam], T.camera)
+        self._L.rt_render_pipe_set_camera(C.byref(self._rp), _p(cam))
+
+    def add_material(self, mat, ind):
+        m = np.array([mat], T.material)
+        self._L.rt_render_pipe_add_material(C.byref(self._rp), _p(m), C.c_ulong(ind))
+
+    def add_light(self, light, lt=T.RT_LT_POINT):
+        l = np.array([light], T.point_light)
+        self._L.rt_render_pipe_add_light(C.byref(self._rp), _p(l), C.c_int(lt))
+
+    def add_primitive(self, prim, pt=T.RT_PT_SPHERE):
+        s = np.array([prim], T.sphere)
+        self._L.rt_render_pipe_add_primitive(C.byref(self._rp), _p(s), C.c_int(pt))
+
+    def add_triangles(self, verts, tris, v_offset, t_offset, v_count, t_count, group):
+        verts = np.ascontiguousarray(verts, T.vertex)
+        tris = np.ascontiguousarray(tris, T.triangle)
+        self._L.rt_render_pipe_add_triangles(C.byref(self._rp), _p(verts), _p(tris), C.c_uint64(v_offset),
+                                             C.c_uint64(t_offset), C.c_uint64(v_count), C.c_uint64(t_count),
+                                             C.c_uint64(group))
+
+    def mesh_add(self, mesh):
+        """rt_mesh_add: the whole mesh with its material slot."""
+        self.add_triangles(mesh.verts, mesh.tris, 0, 0, len(mesh.verts), len(mesh.tris), mesh.group)
+
+    def add_scene(self, scene):
+        """The per-frame add sequence of the reference's draw callback
+        (main.c:674-716): materials, lights, spheres, meshes."""
+        for k in sorted(scene.materials):
+            self.add_material(scene.materials[k], k)
+        for l in scene.lights:
+            self.add_light(l)
+        for s in scene.spheres:
+            self.add_primitive(s)
+        for m in scene.meshes:
+            self.mesh_add(m)
+
+    @property
+    def counts(self):
+        r = self._rp
+        return dict(triangles=r.trianglesCount, vertices=r.vertexCount, prims=r.primsCount, lights=r.lightsCount)
+
+    def kdtree_build(self):
+        """rt_kdtree_build over the current geometry -> (bbox, nodes, idx)."""
+        bb = np.zeros(1, T.box)
+        pn, pi = C.c_void_p(), C.c_void_p()
+        nn, ni = C.c_uint64(), C.c_uint64()
+        self._L.rt_kdtree_build(C.byref(self._rp), _p(bb), C.byref(pn), C.byref(nn), C.byref(pi), C.byref(ni))
+        nodes = _view(pn.value, nn.value, T.cl_kdtree_node).copy()
+        idx = _view(pi.value, ni.value, np.dtype("<u8")).copy()
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(pn)
+        libc.free(pi)
+        return bb[0], nodes, idx
+
+    def draw(self):
+        """rt_render_pipe_draw -> uint8 [h, w, 4] (b,g,r,a); consumes the scene."""
+        ptr = self._L.rt_render_pipe_draw(C.byref(self._rp))
+        w, h = self._rp.w, self._rp.h
+        return _view(ptr, w * h * 4, np.dtype("u1")).reshape(h, w, 4).copy()
+
+    def cleanup(self):
+        if self._open:
+            self._L.rt_render_pipe_cleanup(C.byref(self._rp))
+            self._open = False
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
