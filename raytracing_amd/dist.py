@@ -1,0 +1,65 @@
+"""Multi-GPU frame split: one process per GPU, the scene replicated, the image
+cut into bands of `band_h` rows dealt round-robin to the ranks, and the
+per-rank frame buffers gathered with one collective (RCCL over xGMI when the
+tensors live on GPUs, gloo on CPU in the tests).
+
+The reference renders the whole frame in one NDRange on one device
+(rt_funcs_render_pipe.c:534-565); this module has no counterpart there.
+Pixels are independent, so the only exchange is the gather of finished
+8-bit rows: h*w*4 bytes per frame in total.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+BAND_H = 16
+
+
+def band_rows(h, band_h, n_parts, part):
+    """Global row indices rendered by `part`, in its local storage order
+    (the mapping of rt_hip_set_tile)."""
+    rows = []
+    n_bands = (h + band_h - 1) // band_h
+    for b in range(part, n_bands, n_parts):
+        rows.extend(range(b * band_h, min((b + 1) * band_h, h)))
+    return np.asarray(rows, dtype=np.int64)
+
+
+def local_rows(h, band_h, n_parts, part):
+    return len(band_rows(h, band_h, n_parts, part))
+
+
+def max_local_rows(h, band_h, n_parts):
+    return max(local_rows(h, band_h, n_parts, p) for p in range(n_parts))
+
+
+def assemble(parts, h, w, band_h):
+    """parts[r]: [>= local_rows(r), w, 4] tensor of rank r -> [h, w, 4]."""
+    n = len(parts)
+    out = torch.empty((h, w, 4), dtype=parts[0].dtype, device=parts[0].device)
+    for r in range(n):
+        rows = torch.as_tensor(band_rows(h, band_h, n, r), device=out.device)
+        out[rows] = parts[r][:len(rows)]
+    return out
+
+
+def gather_frame(local, h, w, band_h=BAND_H, dst=0, group=None):
+    """All ranks pass their [rows, w, 4] uint8 tensor (rows may differ by one
+    band between ranks; it is padded to the common maximum).  Rank `dst`
+    returns the assembled [h, w, 4] frame, the others None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local[:h]
+    pad = max_local_rows(h, band_h, world)
+    if local.shape[0] < pad:
+        local = torch.cat([local, local.new_zeros((pad - local.shape[0], w, 4))])
+    elif local.shape[0] > pad:
+        local = local[:pad]
+    local = local.contiguous()
+    # all-to-one: every source uses its own direct link to dst
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return assemble(bufs, h, w, band_h)
