@@ -64,7 +64,8 @@ typedef struct _rt_hip_stats
 	uint64_t triTests;      /* triangle tests     (RT_HIP_STATS only)      */
 	uint64_t spillPushes;   /* stack pushes that went past LDS (STATS)     */
 	uint64_t maxStack;      /* deepest traversal stack seen (STATS)        */
-	uint64_t _reserved;
+	uint64_t nodeVisitsShadow;  /* part of nodeVisits spent in shadow queries (STATS) */
+	uint64_t triTestsShadow;    /* part of triTests spent in shadow queries   (STATS) */
 } rt_hip_stats;
 
 /* rt_hip_render flags */

@@ -18,7 +18,7 @@ class RtError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("raysClosest", "raysShadow", "hits", "nodeVisits", "triTests",
-                 "spillPushes", "maxStack", "_reserved")]
+                 "spillPushes", "maxStack", "nodeVisitsShadow", "triTestsShadow")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if not n.startswith("_")}

@@ -71,7 +71,8 @@ struct Counters
 	uint32_t headClosest[RT_MAX_SLOTS];   // chunk dispenser of k_closest
 	uint32_t hitCount[RT_MAX_SLOTS];      // entries in the hit list of slot k
 	uint32_t headShade[RT_MAX_SLOTS];     // chunk dispenser of k_shade
-	unsigned long long nodeVisits, triTests, spillPushes, maxStack;
+	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
+	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
 };
 
 struct Work
@@ -445,10 +446,15 @@ DEVI f3 fold_weight( const RayEntry &re, f3 P )
 	return F3( expf( re.coef.x * -dist ), expf( re.coef.y * -dist ), expf( re.coef.z * -dist ) );
 }
 
-DEVI void flush_tally( const Work &W, const Tally &tl )
+DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
 {
 	atomicAdd( &W.ctr->nodeVisits, (unsigned long long) tl.nodes );
 	atomicAdd( &W.ctr->triTests, (unsigned long long) tl.tris );
+	if ( shadow )
+	{
+		atomicAdd( &W.ctr->nodeVisitsShadow, (unsigned long long) tl.nodes );
+		atomicAdd( &W.ctr->triTestsShadow, (unsigned long long) tl.tris );
+	}
 	atomicAdd( &W.ctr->spillPushes, (unsigned long long) tl.spills );
 	atomicMax( &W.ctr->maxStack, (unsigned long long) tl.maxSp );
 }
@@ -530,7 +536,7 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int
 			W.hitId[re.pix] = triHit ? (int32_t) trN : ( sphHit ? -2 - (int32_t) prN : -1 );
 	}
 	if ( STATS )
-		flush_tally( W, tl );
+		flush_tally( W, tl, false );
 }
 
 // ---------------------------------------------------------------------------
@@ -734,7 +740,7 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 		push_ray( W, sp, pushRefr, rRefr, re.pix, slot, 0, cRefr, P );
 	}
 	if ( STATS )
-		flush_tally( W, tl );
+		flush_tally( W, tl, true );
 }
 
 // ---------------------------------------------------------------------------
@@ -1240,6 +1246,8 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	out->triTests = h.triTests;
 	out->spillPushes = h.spillPushes;
 	out->maxStack = h.maxStack;
+	out->nodeVisitsShadow = h.nodeVisitsShadow;
+	out->triTestsShadow = h.triTestsShadow;
 	return 0;
 }
 
