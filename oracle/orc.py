@@ -17,7 +17,8 @@ _LIB = None
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits", "staleHits")]
+                ("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits", "staleHits",
+                 "nodeVisitsShadow", "triTestsShadow")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -193,6 +193,7 @@ typedef struct
 	const uint64_t *primsIdx;
 	uint64_t primsCount, lightsCount, trianglesCount;
 	int stackSize, kdStackCap;
+	int inShadow;              /* 1 while a shadow query runs (statistics only) */
 	orc_stats st;
 } pipe_t;
 
@@ -200,6 +201,7 @@ static inline int tri_test( pipe_t *p, const ray_t *r, uint64_t tri, float *t, f
 {
 	const rt_triangle *tr = p->trianglesBuf + tri;
 	++p->st.triTests;
+	p->st.triTestsShadow += p->inShadow;
 	return ray_triangle( r, ld3( &p->vertexBuf[tr->pV0].pos ), ld3( &p->vertexBuf[tr->pV1].pos ),
 		ld3( &p->vertexBuf[tr->pV2].pos ), t, u, v );
 }
@@ -328,15 +330,20 @@ static void alpha_triangles( pipe_t *p, const ray_t *r, float d, float *alpha )
 	if ( !box_ray( &p->boundingBox, r, &tNear, &tFar ) )
 		return;
 	*alpha = 0.0f;
+	p->inShadow = 1;
 	for ( ;; )
 	{
 		const rt_cl_kdtree_node *n = p->nodes + cur;
 		++p->st.nodeVisits;
+		++p->st.nodeVisitsShadow;
 		if ( n->isLast )
 		{
 			add_alpha_in_last( p, r, cur, d, tNear, tFar, alpha );
 			if ( !stackPos )
+			{
+				p->inShadow = 0;
 				return;
+			}
 			--stackPos;
 			cur = stack[stackPos];
 			tNear = tFar;
@@ -724,6 +731,8 @@ static void run_jobs( job_t *proto, int nThreads, orc_stats *stats )
 			stats->triTests += jobs[i].pipe.st.triTests;
 			stats->hits += jobs[i].pipe.st.hits;
 			stats->staleHits += jobs[i].pipe.st.staleHits;
+			stats->nodeVisitsShadow += jobs[i].pipe.st.nodeVisitsShadow;
+			stats->triTestsShadow += jobs[i].pipe.st.triTestsShadow;
 		}
 	}
 	free( th );

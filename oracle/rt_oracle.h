@@ -36,6 +36,8 @@ typedef struct _orc_stats
 	uint64_t hits;          /* shaded hits                                   */
 	uint64_t staleHits;     /* closest-hit queries that ended in the
 	                           "hit flagged but no valid t" state            */
+	uint64_t nodeVisitsShadow;   /* share of nodeVisits in shadow queries    */
+	uint64_t triTestsShadow;     /* share of triTests in shadow queries      */
 } orc_stats;
 
 /* hit-id map encoding (primary ray only) */

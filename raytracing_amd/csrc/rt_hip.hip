@@ -63,6 +63,7 @@ struct DevScene
 	int w, h;                 // full image
 	int localH, bandH, nParts, part;
 	int stackSize;
+	int alphaMonotone;        // every material opacity is >= 0: a shadow sum that reached 1 stays >= 1
 };
 
 struct Counters
@@ -276,6 +277,12 @@ DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float
 	minT = INFINITY;
 	if ( !box_ray( S, r, tNear, tFar ) )
 		return;
+	// A ray that starts inside the scene box has tNear < 0; the reference walks
+	// the cells behind the origin too (its box test does not clamp).  No hit
+	// can be accepted there (t > 0 is required and a leaf only confirms hits
+	// before its own exit distance), so start at the origin instead.
+	if ( tNear < 0.0f )
+		tNear = 0.0f;
 	uint32_t cur = 0;
 	int sp = 0;
 	for ( ;; )
@@ -328,6 +335,15 @@ DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d
 	if ( !box_ray( S, r, tNear, tFar ) )
 		return false;
 	alpha = 0.0f;
+	// Only hits with tNear < t < tFar of their leaf AND t < d count, so the part
+	// of the ray beyond the light cannot contribute: walk [tNear, min(tFar, d)].
+	// Leaves keep the same split distances, hence the same hits are counted.
+	if ( d < tFar )
+		tFar = d;
+	if ( tNear < 0.0f )          // cells behind the origin hold no countable hit (t > 0)
+		tNear = 0.0f;
+	if ( !( tNear < tFar ) )
+		return true;
 	uint32_t cur = 0;
 	int sp = 0;
 	for ( ;; )
@@ -347,6 +363,10 @@ DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d
 				if ( ray_tri( r, v0, e1, e2, t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
 					alpha += S.mats[mat].color.a;
 			}
+			// the caller clamps the sum to [0,1]: with non-negative opacities it
+			// cannot drop below 1 again, the rest of the ray is irrelevant
+			if ( S.alphaMonotone && alpha >= 1.0f )
+				return true;
 			if ( !sp )
 				return true;
 			--sp;
@@ -1004,6 +1024,10 @@ int rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n )
 	HIPCHK( hipSetDevice( c->device ) );
 	if ( upload( c, c->mats, m, n * sizeof( rt_material ) ) ) return 1;
 	c->nMats = n;
+	c->S.alphaMonotone = 1;
+	for ( uint64_t i = 0; i < n; ++i )
+		if ( !( m[i].color.a >= 0.0f ) )
+			c->S.alphaMonotone = 0;
 	c->S.mats = (const rt_material *) c->mats.p;
 	return 0;
 }

@@ -53,8 +53,11 @@ def test_fixture_scenes_match_committed_vectors(name):
     img, ids, st, _ = hip_render(sc, depth, prims)
     same, exact = assert_parity(img, ids, z["img"], z["hit"])
     assert same == 1.0 and exact == 1.0
-    # same work as the restatement: rays, node visits, triangle tests, hits
-    assert [st[k] for k in ("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits")] == z["stats"].tolist()
+    # same rays and hits as the restatement; shadow queries may stop early
+    # (they are cut at the light and at full opacity), never do more work
+    zs = dict(zip(("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits"), z["stats"].tolist()))
+    assert [st[k] for k in ("raysClosest", "raysShadow", "hits")] == [zs[k] for k in ("raysClosest", "raysShadow", "hits")]
+    assert st["nodeVisits"] <= zs["nodeVisits"] and st["triTests"] <= zs["triTests"]
 
 
 @pytest.mark.parametrize("seed,depth", [(1, 10), (2, 18), (3, 26)])
@@ -78,7 +81,11 @@ def test_random_soup_with_spheres_and_two_lights(seed, depth):
     same, exact = assert_parity(img, ids, oimg, oid)
     assert same == 1.0 and exact >= 0.999
     assert st["raysClosest"] == ost["raysClosest"] and st["raysShadow"] == ost["raysShadow"]
-    assert st["triTests"] == ost["triTests"] and st["nodeVisits"] == ost["nodeVisits"]
+    # never more traversal work than the restatement (cells behind the ray
+    # origin and beyond the light are skipped)
+    assert st["triTests"] - st["triTestsShadow"] <= ost["triTests"] - ost["triTestsShadow"]
+    assert st["nodeVisits"] - st["nodeVisitsShadow"] <= ost["nodeVisits"] - ost["nodeVisitsShadow"]
+    assert st["triTestsShadow"] <= ost["triTestsShadow"] and st["nodeVisitsShadow"] <= ost["nodeVisitsShadow"]
 
 
 def test_render_pipe_api_matches_and_consumes_the_scene():

@@ -1,0 +1,37 @@
+"""Development helper: time the benchmark frame for several kd-tree limits."""
+import sys, time
+import numpy as np
+from raytracing_amd import scenes
+from raytracing_amd.pipe import HipRenderer, FlatTree, RT_HIP_STATS, RT_HIP_TIMING
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "config3"
+    combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]] or [(24, 7), (28, 7), (32, 7), (32, 16), (36, 12)]
+    sc = getattr(scenes, name)()
+    v, t = sc.flatten()
+    r = HipRenderer(0)
+    for depth, leaf in combos:
+        t0 = time.time()
+        tree = FlatTree.build(v, t, depth, leaf)
+        tb = time.time() - t0
+        r.load_scene(sc, tree)
+        best = None
+        for _ in range(4):
+            r.render(RT_HIP_TIMING)
+            ms, _ = r.kernel_times()
+            if best is None or ms["frame"] < best["frame"]:
+                best = ms
+        st0 = r.stats()
+        r.render(RT_HIP_STATS)
+        st = r.stats()
+        rays = st0["raysClosest"] + st0["raysShadow"]
+        nc, ns = st["nodeVisits"] - st["nodeVisitsShadow"], st["nodeVisitsShadow"]
+        tc, ts = st["triTests"] - st["triTestsShadow"], st["triTestsShadow"]
+        print(f"{name} depth {depth:2d} leaf {leaf:2d}: build {tb:.2f}s nodes {len(tree.nodes)/1e6:.2f}M refs {len(tree.recs)/1e6:.2f}M "
+              f"| frame {best['frame']:.2f} ms (closest {best['closest']:.2f} shade {best['shade']:.2f}) {rays/best['frame']/1e3:.0f} Mrays/s "
+              f"| closest/ray: {nc/st['raysClosest']:.1f} nodes {tc/st['raysClosest']:.1f} tris; shadow/ray: {ns/max(st['raysShadow'],1):.1f} nodes {ts/max(st['raysShadow'],1):.1f} tris "
+              f"| maxStack {st['maxStack']} spills {st['spillPushes']}", flush=True)
+        tree.release()
+    r.close()
+
+main()
