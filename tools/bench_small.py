@@ -1,0 +1,18 @@
+"""Development helper for profiler passes: renders the benchmark frame a few
+times without the CPU baseline or torch (short process, kernels only)."""
+import sys
+from raytracing_amd import scenes
+from raytracing_amd.pipe import HipRenderer, FlatTree
+
+name = sys.argv[1] if len(sys.argv) > 1 else "config3"
+depth, leaf, frames = (int(x) for x in (sys.argv[2:5] + ["28", "16", "3"][len(sys.argv[2:5]):]))
+sc = getattr(scenes, name)()
+v, t = sc.flatten()
+tree = FlatTree.build(v, t, depth, leaf)
+r = HipRenderer(0)
+r.load_scene(sc, tree)
+for _ in range(frames):
+    r.render(0)
+r.sync()
+print("rendered", frames, "frames", r.stats())
+r.close()
