@@ -285,43 +285,48 @@ DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float
 		tNear = 0.0f;
 	uint32_t cur = 0;
 	int sp = 0;
+	uint2 n = S.nodes[0];
+	if ( STATS ) ++tl.nodes;
 	for ( ;; )
 	{
-		uint2 n = S.nodes[cur];
-		if ( STATS ) ++tl.nodes;
-		if ( ( n.y & 3u ) == 3u )
+		// descend to the next leaf; the whole wave stays in this tight loop
+		// until every lane has reached one, so the leaf scans run together
+		while ( ( n.y & 3u ) != 3u )
 		{
-			uint32_t cnt = n.y >> 2;
-			float lt = INFINITY;
-			for ( uint32_t i = 0; i < cnt; ++i )
-			{
-				f3 v0, e1, e2;
-				uint32_t tri, mat;
-				float t, u, v;
-				load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
-				if ( STATS ) ++tl.tris;
-				if ( ray_tri( r, v0, e1, e2, t, u, v ) && t < lt )
-				{
-					lt = t;
-					minU = u;
-					minV = v;
-					prN = tri;
-					nearestB = 1;
-				}
-			}
-			minT = lt;
-			if ( nearestB && ( minT < tFar ) )
-				return;
-			if ( !sp )
-				return;
-			--sp;
-			uint2 e = stack_pop( st, sp );
-			cur = e.x;
-			tNear = tFar;
-			tFar = __uint_as_float( e.y );
-		}
-		else
 			cur = kd_inner<STATS>( n, cur, r, tNear, tFar, st, sp, tl );
+			n = S.nodes[cur];
+			if ( STATS ) ++tl.nodes;
+		}
+		uint32_t cnt = n.y >> 2;
+		float lt = INFINITY;
+		for ( uint32_t i = 0; i < cnt; ++i )
+		{
+			f3 v0, e1, e2;
+			uint32_t tri, mat;
+			float t, u, v;
+			load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
+			if ( STATS ) ++tl.tris;
+			if ( ray_tri( r, v0, e1, e2, t, u, v ) && t < lt )
+			{
+				lt = t;
+				minU = u;
+				minV = v;
+				prN = tri;
+				nearestB = 1;
+			}
+		}
+		minT = lt;
+		if ( nearestB && ( minT < tFar ) )
+			return;
+		if ( !sp )
+			return;
+		--sp;
+		uint2 e = stack_pop( st, sp );
+		cur = e.x;
+		tNear = tFar;
+		tFar = __uint_as_float( e.y );
+		n = S.nodes[cur];
+		if ( STATS ) ++tl.nodes;
 	}
 }
 
@@ -346,37 +351,40 @@ DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d
 		return true;
 	uint32_t cur = 0;
 	int sp = 0;
+	uint2 n = S.nodes[0];
+	if ( STATS ) ++tl.nodes;
 	for ( ;; )
 	{
-		uint2 n = S.nodes[cur];
-		if ( STATS ) ++tl.nodes;
-		if ( ( n.y & 3u ) == 3u )
+		while ( ( n.y & 3u ) != 3u )
 		{
-			uint32_t cnt = n.y >> 2;
-			for ( uint32_t i = 0; i < cnt; ++i )
-			{
-				f3 v0, e1, e2;
-				uint32_t tri, mat;
-				float t, u, v;
-				load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
-				if ( STATS ) ++tl.tris;
-				if ( ray_tri( r, v0, e1, e2, t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
-					alpha += S.mats[mat].color.a;
-			}
-			// the caller clamps the sum to [0,1]: with non-negative opacities it
-			// cannot drop below 1 again, the rest of the ray is irrelevant
-			if ( S.alphaMonotone && alpha >= 1.0f )
-				return true;
-			if ( !sp )
-				return true;
-			--sp;
-			uint2 e = stack_pop( st, sp );
-			cur = e.x;
-			tNear = tFar;
-			tFar = __uint_as_float( e.y );
-		}
-		else
 			cur = kd_inner<STATS>( n, cur, r, tNear, tFar, st, sp, tl );
+			n = S.nodes[cur];
+			if ( STATS ) ++tl.nodes;
+		}
+		uint32_t cnt = n.y >> 2;
+		for ( uint32_t i = 0; i < cnt; ++i )
+		{
+			f3 v0, e1, e2;
+			uint32_t tri, mat;
+			float t, u, v;
+			load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
+			if ( STATS ) ++tl.tris;
+			if ( ray_tri( r, v0, e1, e2, t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
+				alpha += S.mats[mat].color.a;
+		}
+		// the caller clamps the sum to [0,1]: with non-negative opacities it
+		// cannot drop below 1 again, the rest of the ray is irrelevant
+		if ( S.alphaMonotone && alpha >= 1.0f )
+			return true;
+		if ( !sp )
+			return true;
+		--sp;
+		uint2 e = stack_pop( st, sp );
+		cur = e.x;
+		tNear = tFar;
+		tFar = __uint_as_float( e.y );
+		n = S.nodes[cur];
+		if ( STATS ) ++tl.nodes;
 	}
 }
 
