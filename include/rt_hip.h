@@ -125,9 +125,10 @@ int  rt_hip_sync( rt_hip_ctx *c );
 int  rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host );        /* internal frame buffer -> host, synchronous */
 int  rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host );      /* after RT_HIP_HITIDS */
 int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
-/* after RT_HIP_TIMING: ms[0] = closest-hit passes, ms[1] = shading passes,
- * ms[2] = fold + store, ms[3] = whole frame; launches[i] = launch counts */
-int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[4], int launches[4] );
+/* after RT_HIP_TIMING: ms[0] = closest-hit passes, ms[1] = shadow passes,
+ * ms[2] = shading passes, ms[3] = fold + store, ms[4] = whole frame;
+ * launches[i] = launch counts */
+int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );
 
 #ifdef __cplusplus
 }

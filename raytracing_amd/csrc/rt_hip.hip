@@ -6,9 +6,11 @@
 //   for slot k = 0 .. STACK_SIZE-1            (slot = index in the pixel's ray list)
 //     k_closest<k>  ray list k  -> closest hit (spheres brute force + kd tree)
 //                   misses finish their slot, hits are COMPACTED into a hit list
-//     k_shade<k>    hit list k  -> hit point, normal, one shadow traversal per
-//                   light, Phong terms; child rays are appended (wave-aggregated
-//                   atomics) to the ray lists of the slots they occupy
+//     k_shadow<k>   hit list k x lights -> one shadow traversal per item (lean
+//                   register state: only what the traversal needs)
+//     k_shade<k>    hit list k  -> hit point, normal, Phong terms; child rays are
+//                   appended (wave-aggregated atomics) to the ray lists of the
+//                   slots they occupy; no traversal, pure streaming
 //   k_fold          per pixel: fold child colours into parents back to front,
 //                   clamp, truncate to 8-bit BGRA
 //
@@ -72,6 +74,7 @@ struct Counters
 	uint32_t headClosest[RT_MAX_SLOTS];   // chunk dispenser of k_closest
 	uint32_t hitCount[RT_MAX_SLOTS];      // entries in the hit list of slot k
 	uint32_t headShade[RT_MAX_SLOTS];     // chunk dispenser of k_shade
+	uint32_t headShadow[RT_MAX_SLOTS];    // chunk dispenser of k_shadow
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
 };
@@ -84,6 +87,7 @@ struct Work
 	uint2  *hitB;                         // (id | sphere flag, b)
 	float4 *res;                          // [slot * npix + pix] (col rgb, parent slot)
 	float4 *fac;                          // [slot * npix + pix] weight of this slot in its parent
+	float  *shadow;                       // [light * npix + hit] summed shadow opacity
 	uint32_t *stackPos;                   // last used slot of each pixel
 	int32_t *hitId;                       // optional primary hit ids
 	uint2  *spill;                        // traversal stack overflow
@@ -238,16 +242,21 @@ DEVI void load_rec( const float4 *recs, uint32_t i, f3 &v0, f3 &e1, f3 &e2, uint
 	mat = __float_as_uint( c.z );
 }
 
+// component `axis` of a vector held in registers.  Written on values, not on
+// struct members behind a reference: selecting between member loads gets
+// turned into a dynamically indexed load, which forces the ray into scratch.
+DEVI float pick( uint32_t axis, float x, float y, float z ) { return axis == 0u ? x : ( axis == 1u ? y : z ); }
+
 // inner-node step shared by both traversals (CL/rt_funcs_primitives.cl:185-251)
 template <bool STATS>
-DEVI uint32_t kd_inner( uint2 n, uint32_t cur, const Ray &r, float tNear, float &tFar,
+DEVI uint32_t kd_inner( uint2 n, uint32_t cur, f3 src, f3 inv, f3 dest, float tNear, float &tFar,
 	const StackRef &st, int &sp, Tally &tl )
 {
 	uint32_t axis = n.y & 3u;
 	float sep = __uint_as_float( n.x );
-	float o = axis == 0u ? r.src.x : ( axis == 1u ? r.src.y : r.src.z );
-	float iv = axis == 0u ? r.inv.x : ( axis == 1u ? r.inv.y : r.inv.z );
-	float d = axis == 0u ? r.dest.x : ( axis == 1u ? r.dest.y : r.dest.z );
+	float o = pick( axis, src.x, src.y, src.z );
+	float iv = pick( axis, inv.x, inv.y, inv.z );
+	float d = pick( axis, dest.x, dest.y, dest.z );
 	float tSplit = ( sep - o ) * iv;
 	uint32_t nearN = cur + 1u, farN = n.y >> 2;
 	if ( d < 0.0f )
@@ -270,7 +279,7 @@ DEVI uint32_t kd_inner( uint2 n, uint32_t cur, const Ray &r, float tNear, float 
 // loop :74-111 inlined.  The per-leaf reset of the running distance while the
 // hit flag and the triangle id persist is the reference's behaviour.
 template <bool STATS>
-DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float &minT, float &minU,
+DEVI void kd_nearest( const DevScene &S, const Ray r, const StackRef &st, float &minT, float &minU,
 	float &minV, uint32_t &prN, int &nearestB, Tally &tl )
 {
 	float tNear, tFar;
@@ -283,6 +292,7 @@ DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float
 	// before its own exit distance), so start at the origin instead.
 	if ( tNear < 0.0f )
 		tNear = 0.0f;
+	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	uint32_t cur = 0;
 	int sp = 0;
 	uint2 n = S.nodes[0];
@@ -293,7 +303,7 @@ DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float
 		// until every lane has reached one, so the leaf scans run together
 		while ( ( n.y & 3u ) != 3u )
 		{
-			cur = kd_inner<STATS>( n, cur, r, tNear, tFar, st, sp, tl );
+			cur = kd_inner<STATS>( n, cur, src, inv, dest, tNear, tFar, st, sp, tl );
 			n = S.nodes[cur];
 			if ( STATS ) ++tl.nodes;
 		}
@@ -334,7 +344,7 @@ DEVI void kd_nearest( const DevScene &S, const Ray &r, const StackRef &st, float
 // CL/rt_funcs_primitives.cl:278-379 + :256-276.  Returns false (alpha
 // untouched) when the ray misses the scene box.
 template <bool STATS>
-DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d, float &alpha, Tally &tl )
+DEVI bool kd_alpha( const DevScene &S, const Ray r, const StackRef &st, float d, float &alpha, Tally &tl )
 {
 	float tNear, tFar;
 	if ( !box_ray( S, r, tNear, tFar ) )
@@ -349,6 +359,7 @@ DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d
 		tNear = 0.0f;
 	if ( !( tNear < tFar ) )
 		return true;
+	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	uint32_t cur = 0;
 	int sp = 0;
 	uint2 n = S.nodes[0];
@@ -357,7 +368,7 @@ DEVI bool kd_alpha( const DevScene &S, const Ray &r, const StackRef &st, float d
 	{
 		while ( ( n.y & 3u ) != 3u )
 		{
-			cur = kd_inner<STATS>( n, cur, r, tNear, tFar, st, sp, tl );
+			cur = kd_inner<STATS>( n, cur, src, inv, dest, tNear, tFar, st, sp, tl );
 			n = S.nodes[cur];
 			if ( STATS ) ++tl.nodes;
 		}
@@ -424,54 +435,53 @@ DEVI bool slot0_pixel( const DevScene &S, const Work &W, uint32_t e, int &x, int
 	return x < S.w && yLocal < S.localH && yGlobal < S.h;
 }
 
-struct RayEntry
+// Head of a ray-list entry: what a traversal needs.  pk = parent slot | type << 8
+// (type 1 = reflection, 0 = refraction); slot 0 has no parent (0xff).
+struct RayHead
 {
 	Ray ray;
-	uint32_t pix;
-	int parent, type;      // parent slot (-1 for slot 0), 1 = reflection, 0 = refraction
-	f3 coef;               // reflection: parent reflect rgb; refraction: parent color rgb * lightFalloff
-	f3 parentP;            // parent hit point (refraction weight needs the distance)
+	uint32_t pix, pk;
 };
 
-DEVI bool load_entry( const DevScene &S, const Work &W, int slot, uint32_t e, uint32_t count, RayEntry &re )
+DEVI int parent_of( uint32_t pk ) { return ( pk & 0xffu ) == 0xffu ? -1 : (int) ( pk & 0xffu ); }
+
+DEVI bool load_ray( const DevScene &S, const Work &W, int slot, uint32_t e, uint32_t count, RayHead &rh )
 {
 	if ( slot == 0 )
 	{
 		int x, yl, yg;
 		if ( !slot0_pixel( S, W, e, x, yl, yg ) )
 			return false;
-		re.ray = primary_ray( S, x, yg );
-		re.pix = (uint32_t) yl * (uint32_t) S.w + (uint32_t) x;
-		re.parent = -1;
-		re.type = 1;
-		re.coef = F3( 0.0f, 0.0f, 0.0f );
-		re.parentP = F3( 0.0f, 0.0f, 0.0f );
+		rh.ray = primary_ray( S, x, yg );
+		rh.pix = (uint32_t) yl * (uint32_t) S.w + (uint32_t) x;
+		rh.pk = 0x1ffu;
 		return true;
 	}
 	if ( e >= count )
 		return false;
 	size_t o = (size_t) ( slot - 1 ) * W.npix + e;
-	float4 a = W.rayA[o], b = W.rayB[o], c = W.rayC[o], d = W.rayD[o];
-	re.ray.src = F3( a.x, a.y, a.z );
-	re.ray.dest = F3( b.x, b.y, b.z );
-	re.ray.inv = rcp3( re.ray.dest );
-	re.pix = __float_as_uint( a.w );
-	uint32_t pk = __float_as_uint( b.w );
-	re.parent = (int) ( pk & 0xffu );
-	re.type = (int) ( ( pk >> 8 ) & 1u );
-	re.coef = F3( c.x, c.y, c.z );
-	re.parentP = F3( d.x, d.y, d.z );
+	float4 a = W.rayA[o], b = W.rayB[o];
+	rh.ray.src = F3( a.x, a.y, a.z );
+	rh.ray.dest = F3( b.x, b.y, b.z );
+	rh.ray.inv = rcp3( rh.ray.dest );
+	rh.pix = __float_as_uint( a.w );
+	rh.pk = __float_as_uint( b.w );
 	return true;
 }
 
 // weight with which this slot's colour is folded into its parent
-// (CL/rt_funcs_primitives.cl:693-720); P is this slot's hit point
-DEVI f3 fold_weight( const RayEntry &re, f3 P )
+// (CL/rt_funcs_primitives.cl:693-720); P is this slot's hit point.
+// rayC = reflection: parent reflect rgb / refraction: parent color rgb * lightFalloff,
+// rayD = parent hit point (the refraction weight needs the distance).
+DEVI f3 fold_weight( const Work &W, int slot, uint32_t e, uint32_t pk, f3 P )
 {
-	if ( re.type == 1 )
-		return re.coef;
-	float dist = len3( sub3( re.parentP, P ) );
-	return F3( expf( re.coef.x * -dist ), expf( re.coef.y * -dist ), expf( re.coef.z * -dist ) );
+	size_t o = (size_t) ( slot - 1 ) * W.npix + e;
+	float4 c = W.rayC[o];
+	if ( ( pk >> 8 ) & 1u )
+		return F3( c.x, c.y, c.z );
+	float4 d = W.rayD[o];
+	float dist = len3( sub3( F3( d.x, d.y, d.z ), P ) );
+	return F3( expf( c.x * -dist ), expf( c.y * -dist ), expf( c.z * -dist ) );
 }
 
 DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
@@ -487,6 +497,26 @@ DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
 	atomicMax( &W.ctr->maxStack, (unsigned long long) tl.maxSp );
 }
 
+DEVI StackRef make_stack( uint2 *lds, const Work &W )
+{
+	StackRef st;
+	st.lds = lds + threadIdx.x;
+	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
+	st.stride = W.spillStride;
+	return st;
+}
+
+// every wave pulls 64-entry chunks until the list is exhausted
+DEVI bool next_chunk( uint32_t *head, unsigned long long total, uint32_t &first )
+{
+	uint32_t chunk = 0;
+	if ( lane_id() == 0u )
+		chunk = atomicAdd( head, 1u );
+	chunk = wave_bcast( chunk );
+	first = chunk * 64u;
+	return (unsigned long long) chunk * 64ull < total;
+}
+
 // ---------------------------------------------------------------------------
 // k_closest: closest-hit pass of one slot
 // ---------------------------------------------------------------------------
@@ -494,26 +524,17 @@ template <bool STATS>
 __global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int slot, int wantIds )
 {
 	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
-	StackRef st;
-	st.lds = s_stack + threadIdx.x;
-	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
-	st.stride = W.spillStride;
+	const StackRef st = make_stack( s_stack, W );
 	Tally tl = { 0u, 0u, 0u, 0u };
 
 	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
-
-	for ( ;; )
+	uint32_t first;
+	while ( next_chunk( &W.ctr->headClosest[slot], count, first ) )
 	{
-		uint32_t chunk = 0;
-		if ( lane_id() == 0u )
-			chunk = atomicAdd( &W.ctr->headClosest[slot], 1u );
-		chunk = wave_bcast( chunk );
-		if ( (unsigned long long) chunk * 64ull >= count )
-			break;
-		uint32_t e = chunk * 64u + lane_id();
-
-		RayEntry re;
-		bool valid = load_entry( S, W, slot, e, count, re );
+		const uint32_t e = first + lane_id();
+		RayHead rh;
+		rh.pix = rh.pk = 0u;
+		const bool valid = load_ray( S, W, slot, e, count, rh );
 
 		float prMinT = INFINITY, trMinT = INFINITY, trU = 0.0f, trV = 0.0f;
 		uint32_t prN = 0u, trN = 0u;
@@ -525,7 +546,7 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int
 			for ( int i = 0; i < S.nSpheres; ++i )
 			{
 				float t;
-				int b = ray_sphere( re.ray, S.spheres[i], t );
+				int b = ray_sphere( rh.ray, S.spheres[i], t );
 				if ( b && t < prMinT )
 				{
 					prMinT = t;
@@ -533,16 +554,16 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int
 					prB = b;
 				}
 			}
-			kd_nearest<STATS>( S, re.ray, st, trMinT, trU, trV, trN, trB, tl );
+			kd_nearest<STATS>( S, rh.ray, st, trMinT, trU, trV, trN, trB, tl );
 		}
 
 		// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
 		// "flag set, no valid distance, no sphere" is shaded as a miss
-		bool triHit = valid && ( trB || prB ) && ( trMinT < prMinT );
-		bool sphHit = valid && ( trB || prB ) && !( trMinT < prMinT ) && prB;
-		bool hit = triHit || sphHit;
+		const bool triHit = valid && ( trB || prB ) && ( trMinT < prMinT );
+		const bool sphHit = valid && ( trB || prB ) && !( trMinT < prMinT ) && prB;
+		const bool hit = triHit || sphHit;
 
-		uint32_t hidx = wave_append( &W.ctr->hitCount[slot], hit );
+		const uint32_t hidx = wave_append( &W.ctr->hitCount[slot], hit );
 		if ( hit )
 		{
 			W.hitA[hidx] = make_float4( __uint_as_float( e ), triHit ? trMinT : prMinT, trU, trV );
@@ -550,58 +571,106 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int
 		}
 		else if ( valid )
 		{
-			size_t o = (size_t) slot * W.npix + re.pix;
-			W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( re.parent ) );
+			const size_t o = (size_t) slot * W.npix + rh.pix;
+			W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( parent_of( rh.pk ) ) );
 			if ( slot == 0 )
-				W.stackPos[re.pix] = 0u;
+				W.stackPos[rh.pix] = 0u;
 			else
 			{
-				f3 fw = fold_weight( re, F3( 0.0f, 0.0f, 0.0f ) );
+				f3 fw = fold_weight( W, slot, e, rh.pk, F3( 0.0f, 0.0f, 0.0f ) );
 				W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
 			}
 		}
 		if ( slot == 0 && wantIds && valid )
-			W.hitId[re.pix] = triHit ? (int32_t) trN : ( sphHit ? -2 - (int32_t) prN : -1 );
+			W.hitId[rh.pix] = triHit ? (int32_t) trN : ( sphHit ? -2 - (int32_t) prN : -1 );
 	}
 	if ( STATS )
 		flush_tally( W, tl, false );
 }
 
 // ---------------------------------------------------------------------------
-// k_shade: lighting of the compacted hits of one slot + child ray generation
+// k_shadow: one shadow query per (hit, light) of one slot
 // ---------------------------------------------------------------------------
 
-// CL/rt_funcs_primitives.cl:450-564
-template <bool STATS>
-DEVI f3 light_point( const DevScene &S, const StackRef &st, f3 P, f3 N, const rt_material &mat, f3 viewer, Tally &tl )
+// light record: 3 x float4 = (col b,g,r,a) (pos.xyz,_) (rad,_,_,_)
+DEVI void to_light( const DevScene &S, int o, f3 P, f3 &toLight, float &d )
 {
-	f3 col = F3( 0.0f, 0.0f, 0.0f );
-	for ( int o = 0; o < S.nLights; ++o )
+	float4 lp = S.lights[3 * o + 1];
+	toLight = sub3( F3( lp.x, lp.y, lp.z ), P );
+	d = len3( toLight );
+	toLight = div3( toLight, d );
+}
+
+// Item i = light (i / hits) of hit (i % hits).  Stores the two clamped opacity
+// sums of CL/rt_funcs_primitives.cl:481-502 added together; the variable that
+// carries the sphere sum keeps it when the ray misses the scene box, so the
+// sphere opacity is then counted twice, as in the reference.
+template <bool STATS>
+__global__ __launch_bounds__( RT_BLOCK ) void k_shadow( DevScene S, Work W, int slot )
+{
+	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
+	const StackRef st = make_stack( s_stack, W );
+	Tally tl = { 0u, 0u, 0u, 0u };
+
+	const uint32_t hits = W.ctr->hitCount[slot];
+	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
+	const unsigned long long total = (unsigned long long) hits * (unsigned long long) S.nLights;
+	uint32_t first;
+	while ( next_chunk( &W.ctr->headShadow[slot], total, first ) )
 	{
-		float4 lc = S.lights[3 * o], lp = S.lights[3 * o + 1], lr = S.lights[3 * o + 2];
-		f3 lcol = F3( lc.z, lc.y, lc.x );          // stored b,g,r,a
-		float rad = lr.x;
+		const uint32_t i = first + lane_id();
+		if ( i >= total )
+			continue;
+		const uint32_t o = i / hits, h = i - o * hits;
+		const float4 ha = W.hitA[h];
+		RayHead rh;
+		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
+			continue;
+		const f3 P = add3( mul3( rh.ray.dest, ha.y ), rh.ray.src );
 
-		f3 toLight = sub3( F3( lp.x, lp.y, lp.z ), P );
-		float d = len3( toLight );
-		toLight = div3( toLight, d );
-
-		// shadow ray :481-504; `a` keeps the sphere sum when the ray misses the scene box
+		f3 toLight;
+		float d;
+		to_light( S, (int) o, P, toLight, d );
 		Ray sh;
 		sh.dest = toLight;
 		sh.src = add3( P, mul3( toLight, EPSILON ) );
 		sh.inv = rcp3( toLight );
 		float a = 0.0f;
-		for ( int i = 0; i < S.nSpheres; ++i )
+		for ( int k = 0; k < S.nSpheres; ++k )           // :418-448
 		{
 			float t;
-			int b = ray_sphere( sh, S.spheres[i], t );
+			int b = ray_sphere( sh, S.spheres[k], t );
 			if ( b && t < d )
-				a += S.mats[S.sphereMat[i]].color.a;
+				a += S.mats[S.sphereMat[k]].color.a;
 		}
 		float shadowed = clampf( a, 0.0f, 1.0f );
 		kd_alpha<STATS>( S, sh, st, d, a, tl );
 		shadowed += clampf( a, 0.0f, 1.0f );
+		W.shadow[(size_t) o * W.npix + h] = shadowed;
+	}
+	if ( STATS )
+		flush_tally( W, tl, true );
+}
+
+// ---------------------------------------------------------------------------
+// k_shade: lighting of the compacted hits of one slot + child ray generation
+// ---------------------------------------------------------------------------
+
+// CL/rt_funcs_primitives.cl:450-564 with the shadow term taken from k_shadow
+DEVI f3 light_point( const DevScene &S, const Work &W, uint32_t h, f3 P, f3 N, const rt_material &mat, f3 viewer )
+{
+	f3 col = F3( 0.0f, 0.0f, 0.0f );
+	for ( int o = 0; o < S.nLights; ++o )
+	{
+		float4 lc = S.lights[3 * o], lr = S.lights[3 * o + 2];
+		f3 lcol = F3( lc.z, lc.y, lc.x );          // stored b,g,r,a
+		float rad = lr.x;
+
+		f3 toLight;
+		float d;
+		to_light( S, o, P, toLight, d );
+
+		float shadowed = W.shadow[(size_t) o * W.npix + h];
 		shadowed *= mat.color.a;
 
 		f3 ambient = col_mult( lcol, rgb_of( mat.ambient ) );
@@ -648,39 +717,25 @@ DEVI void push_ray( const Work &W, int target, bool want, const Ray &r, uint32_t
 	}
 }
 
-template <bool STATS>
 __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int slot )
 {
-	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
-	StackRef st;
-	st.lds = s_stack + threadIdx.x;
-	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
-	st.stride = W.spillStride;
-	Tally tl = { 0u, 0u, 0u, 0u };
-
 	const uint32_t count = W.ctr->hitCount[slot];
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
-
-	for ( ;; )
+	uint32_t first;
+	while ( next_chunk( &W.ctr->headShade[slot], count, first ) )
 	{
-		uint32_t chunk = 0;
-		if ( lane_id() == 0u )
-			chunk = atomicAdd( &W.ctr->headShade[slot], 1u );
-		chunk = wave_bcast( chunk );
-		if ( (unsigned long long) chunk * 64ull >= count )
-			break;
-		uint32_t h = chunk * 64u + lane_id();
+		const uint32_t h = first + lane_id();
 		bool valid = h < count;
 
-		RayEntry re;
-		re.pix = 0u;
+		RayHead rh;
+		rh.pix = rh.pk = 0u;
 		float4 ha = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
 		uint2 hb = make_uint2( 0u, 0u );
 		if ( valid )
 		{
 			ha = W.hitA[h];
 			hb = W.hitB[h];
-			valid = load_entry( S, W, slot, __float_as_uint( ha.x ), rayCount, re );
+			valid = load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh );
 		}
 
 		bool pushRefl = false, pushRefr = false;
@@ -692,36 +747,35 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 		{
 			f3 N;
 			uint32_t matIdx;
-			int bNearest = (int) hb.y;
-			float t = ha.y;
+			const int bNearest = (int) hb.y;
+			const float t = ha.y;
 
+			// hit point: dest * t + src for triangles (:66) and spheres (:42-43) alike
+			P = add3( mul3( rh.ray.dest, t ), rh.ray.src );
 			if ( hb.x & 0x80000000u )
 			{
-				// sphere hit point and normal, CL/rt_funcs_primitives.cl:31-49
-				uint32_t si = hb.x & 0x7fffffffu;
-				float4 s = S.spheres[si];
+				// sphere normal, CL/rt_funcs_primitives.cl:45-46
+				const uint32_t si = hb.x & 0x7fffffffu;
+				const float4 s = S.spheres[si];
 				matIdx = S.sphereMat[si];
-				P = mul3( re.ray.dest, t );
-				P = add3( P, re.ray.src );
 				N = div3( sub3( P, F3( s.x, s.y, s.z ) ), s.w );
 				N = mul3( N, (float) bNearest );
 			}
 			else
 			{
-				// triangle hit point, barycentric normal (not normalised), :62-72
+				// barycentric normal (not normalised), :68-71
 				const float4 *sp4 = S.shade + 3u * (size_t) hb.x;
-				float4 a = sp4[0], b = sp4[1], c = sp4[2];
-				f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
-				float u = ha.z, v = ha.w;
+				const float4 a = sp4[0], b = sp4[1], c = sp4[2];
+				const f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
+				const float u = ha.z, v = ha.w;
 				matIdx = __float_as_uint( c.y );
-				P = add3( mul3( re.ray.dest, t ), re.ray.src );
 				N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
 			}
 
-			rt_material mat = S.mats[matIdx];
-			f3 col = light_point<STATS>( S, st, P, N, mat, re.ray.src, tl );
+			const rt_material mat = S.mats[matIdx];
+			const f3 col = light_point( S, W, h, P, N, mat, rh.ray.src );
 
-			sp = slot == 0 ? 0 : (int) W.stackPos[re.pix];
+			sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
 
 			// reflection ray :643-655
 			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 )
@@ -729,21 +783,21 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 			{
 				++sp;
 				pushRefl = true;
-				rRefl.dest = reflect3( re.ray.dest, N );
+				rRefl.dest = reflect3( rh.ray.dest, N );
 				rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
 				cRefl = rgb_of( mat.reflect );
 			}
 			// refraction ray :657-677
 			if ( ( ( sp + 1 ) < S.stackSize ) && ( mat.color.a < 0.99f ) )
 			{
-				float nRel = ENV_OPT_DENSITY / mat.optDens;
-				float cosI = dot3( N, re.ray.dest );
-				float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
+				const float nRel = ENV_OPT_DENSITY / mat.optDens;
+				const float cosI = dot3( N, rh.ray.dest );
+				const float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
 				if ( sinT < 1.0f )
 				{
 					++sp;
 					pushRefr = true;
-					rRefr.dest = norm3( sub3( mul3( re.ray.dest, nRel ),
+					rRefr.dest = norm3( sub3( mul3( rh.ray.dest, nRel ),
 						mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
 					rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
 					cRefr = F3( mat.color.r * mat.lightFalloff, mat.color.g * mat.lightFalloff,
@@ -751,24 +805,22 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 				}
 			}
 
-			size_t o = (size_t) slot * W.npix + re.pix;
-			W.res[o] = make_float4( col.x, col.y, col.z, __int_as_float( re.parent ) );
+			const size_t o = (size_t) slot * W.npix + rh.pix;
+			W.res[o] = make_float4( col.x, col.y, col.z, __int_as_float( parent_of( rh.pk ) ) );
 			if ( slot > 0 )
 			{
-				f3 fw = fold_weight( re, P );
+				const f3 fw = fold_weight( W, slot, __float_as_uint( ha.x ), rh.pk, P );
 				W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
 			}
 			if ( slot == 0 || pushRefl || pushRefr )
-				W.stackPos[re.pix] = (uint32_t) sp;
+				W.stackPos[rh.pix] = (uint32_t) sp;
 		}
 
 		// slot numbers: reflection takes the first new slot, refraction the next
-		int reflSlot = sp - ( pushRefr ? 1 : 0 );
-		push_ray( W, reflSlot, pushRefl, rRefl, re.pix, slot, 1, cRefl, P );
-		push_ray( W, sp, pushRefr, rRefr, re.pix, slot, 0, cRefr, P );
+		const int reflSlot = sp - ( pushRefr ? 1 : 0 );
+		push_ray( W, reflSlot, pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
+		push_ray( W, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
 	}
-	if ( STATS )
-		flush_tally( W, tl, true );
 }
 
 // ---------------------------------------------------------------------------
@@ -853,15 +905,16 @@ struct rt_hip_ctx
 	DevScene S;
 	Work W;
 	DevBuf nodes, recs, shade, mats, spheres, sphereMat, lights;
-	DevBuf ctr, rays, hitA, hitB, res, fac, stackPos, hitId, spill, frame;
+	DevBuf ctr, rays, hitA, hitB, res, fac, shadow, stackPos, hitId, spill, frame;
 	uint64_t nNodes = 0, nRecs = 0, nTris = 0, nMats = 0;
 	uint64_t maxMatTree = 0, maxMatSphere = 0;   // highest material slot referenced
 	int treeDepth = 0;
 	int allocStack = 0;           // stack size the work buffers were sized for
 	bool workDirty = true;
-	int gridClosest[2] = { 0, 0 }, gridShade[2] = { 0, 0 };
+	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridShade = 0;
+	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
-	hipEvent_t ev[2 * RT_MAX_SLOTS + 3] = {};
+	hipEvent_t ev[3 * RT_MAX_SLOTS + 3] = {};
 	bool haveEvents = false, timed = false;
 	int timedSlots = 0;
 	uint32_t validPixels = 0;
@@ -942,9 +995,10 @@ rt_hip_ctx *rt_hip_create( int device )
 
 	// persistent grids: one resident wave set per CU, as many blocks as fit
 	int occ = 0;
-	struct { const void *f; int *dst; } ks[4] = {
+	struct { const void *f; int *dst; } ks[5] = {
 		{ (const void *) k_closest<false>, &c->gridClosest[0] }, { (const void *) k_closest<true>, &c->gridClosest[1] },
-		{ (const void *) k_shade<false>, &c->gridShade[0] }, { (const void *) k_shade<true>, &c->gridShade[1] } };
+		{ (const void *) k_shadow<false>, &c->gridShadow[0] }, { (const void *) k_shadow<true>, &c->gridShadow[1] },
+		{ (const void *) k_shade, &c->gridShade } };
 	for ( auto &k : ks )
 	{
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
@@ -963,7 +1017,7 @@ void rt_hip_destroy( rt_hip_ctx *c )
 	(void) hipSetDevice( c->device );
 	(void) hipStreamSynchronize( c->stream );
 	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights,
-		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->res, &c->fac, &c->stackPos, &c->hitId, &c->spill, &c->frame };
+		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->res, &c->fac, &c->shadow, &c->stackPos, &c->hitId, &c->spill, &c->frame };
 	for ( DevBuf *b : all )
 		if ( b->p ) (void) hipFree( b->p );
 	if ( c->haveEvents )
@@ -1155,6 +1209,7 @@ static int prepare_work( rt_hip_ctx *c )
 	if ( ensure( c, c->hitB, sizeof( uint2 ) * npix ) ) return 1;
 	if ( ensure( c, c->res, sizeof( float4 ) * npix * slots ) ) return 1;
 	if ( ensure( c, c->fac, sizeof( float4 ) * npix * slots ) ) return 1;
+	if ( ensure( c, c->shadow, sizeof( float ) * npix * (size_t) ( S.nLights > 0 ? S.nLights : 1 ) ) ) return 1;
 	if ( ensure( c, c->stackPos, sizeof( uint32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->hitId, sizeof( int32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->frame, sizeof( rt_argb ) * npix ) ) return 1;
@@ -1169,6 +1224,8 @@ static int prepare_work( rt_hip_ctx *c )
 	W.hitB = (uint2 *) c->hitB.p;
 	W.res = (float4 *) c->res.p;
 	W.fac = (float4 *) c->fac.p;
+	W.shadow = (float *) c->shadow.p;
+	c->workLights = S.nLights;
 	W.stackPos = (uint32_t *) c->stackPos.p;
 	W.hitId = (int32_t *) c->hitId.p;
 	W.spill = (uint2 *) c->spill.p;
@@ -1193,7 +1250,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	HIPCHK( hipSetDevice( c->device ) );
 	if ( c->S.nSpheres == 0 && !c->S.spheres ) { rt_sphere z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_spheres( c, &z, 0 ) ) return 1; }
 	if ( c->S.nLights == 0 && !c->S.lights ) { rt_point_light z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_lights( c, &z, 0 ) ) return 1; }
-	if ( c->workDirty && prepare_work( c ) ) return 1;
+	if ( ( c->workDirty || c->workLights != c->S.nLights ) && prepare_work( c ) ) return 1;
 	const bool stats = flags & RT_HIP_STATS, ids = flags & RT_HIP_HITIDS, timing = flags & RT_HIP_TIMING;
 	const DevScene &S = c->S;
 	const Work &W = c->W;
@@ -1216,15 +1273,18 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	{
 		// a persistent grid never needs more waves than there are chunks
 		uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
-		int gc = c->gridClosest[stats], gs = c->gridShade[stats];
+		int gc = c->gridClosest[stats], gw = c->gridShadow[stats], gs = c->gridShade;
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
+		if ( k == 0 && want * (uint32_t) ( S.nLights > 0 ? S.nLights : 1 ) < (uint32_t) gw ) gw = (int) ( want ? want * ( S.nLights > 0 ? S.nLights : 1 ) : 1u );
 		if ( k == 0 && want < (uint32_t) gs ) gs = (int) ( want ? want : 1u );
 		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
 		if ( stats ) hipLaunchKernelGGL( k_closest<true>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
 		else hipLaunchKernelGGL( k_closest<false>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
 		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
-		if ( stats ) hipLaunchKernelGGL( k_shade<true>, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
-		else hipLaunchKernelGGL( k_shade<false>, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
+		if ( stats ) hipLaunchKernelGGL( k_shadow<true>, dim3( gw ), dim3( RT_BLOCK ), 0, s, S, W, k );
+		else hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, s, S, W, k );
+		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+		hipLaunchKernelGGL( k_shade, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
 	}
 	if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
 	hipLaunchKernelGGL( k_fold, dim3( ( W.npix + RT_BLOCK - 1 ) / RT_BLOCK ), dim3( RT_BLOCK ), 0, s, W, out, S.stackSize );
@@ -1283,27 +1343,28 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	return 0;
 }
 
-int rt_hip_kernel_times( rt_hip_ctx *c, float ms[4], int launches[4] )
+int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 {
 	if ( !c || !ms || !launches ) return fail( "rt_hip_kernel_times: bad arguments" );
 	if ( !c->timed ) return fail( "rt_hip_kernel_times: last render was not timed" );
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
-	ms[0] = ms[1] = ms[2] = ms[3] = 0.0f;
+	for ( int i = 0; i < 5; ++i ) ms[i] = 0.0f;
 	int n = c->timedSlots, e = 0;
 	for ( int k = 0; k < n; ++k )
 	{
-		float a = 0.0f, b = 0.0f;
-		HIPCHK( hipEventElapsedTime( &a, c->ev[e], c->ev[e + 1] ) );
-		HIPCHK( hipEventElapsedTime( &b, c->ev[e + 1], c->ev[e + 2] ) );
-		ms[0] += a;
-		ms[1] += b;
-		e += 2;
+		float t[3] = { 0.0f, 0.0f, 0.0f };
+		for ( int j = 0; j < 3; ++j )
+		{
+			HIPCHK( hipEventElapsedTime( &t[j], c->ev[e + j], c->ev[e + j + 1] ) );
+			ms[j] += t[j];
+		}
+		e += 3;
 	}
-	HIPCHK( hipEventElapsedTime( &ms[2], c->ev[e], c->ev[e + 1] ) );
-	HIPCHK( hipEventElapsedTime( &ms[3], c->ev[0], c->ev[e + 1] ) );
-	launches[0] = launches[1] = n;
-	launches[2] = 1;
-	launches[3] = 2 * n + 1;
+	HIPCHK( hipEventElapsedTime( &ms[3], c->ev[e], c->ev[e + 1] ) );
+	HIPCHK( hipEventElapsedTime( &ms[4], c->ev[0], c->ev[e + 1] ) );
+	launches[0] = launches[1] = launches[2] = n;
+	launches[3] = 1;
+	launches[4] = 3 * n + 1;
 	return 0;
 }

@@ -208,11 +208,11 @@ class HipRenderer:
         return st.as_dict()
 
     def kernel_times(self):
-        """After render(RT_HIP_TIMING): ({closest, shade, fold, frame} ms, launch counts)."""
-        ms = (C.c_float * 4)()
-        n = (C.c_int * 4)()
+        """After render(RT_HIP_TIMING): ({closest, shadow, shade, fold, frame} ms, launch counts)."""
+        ms = (C.c_float * 5)()
+        n = (C.c_int * 5)()
         check(self._L.rt_hip_kernel_times(self._c, ms, n), "rt_hip_kernel_times")
-        names = ("closest", "shade", "fold", "frame")
+        names = ("closest", "shadow", "shade", "fold", "frame")
         return dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n]))
 
 

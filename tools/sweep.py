@@ -28,7 +28,7 @@ def main():
         nc, ns = st["nodeVisits"] - st["nodeVisitsShadow"], st["nodeVisitsShadow"]
         tc, ts = st["triTests"] - st["triTestsShadow"], st["triTestsShadow"]
         print(f"{name} depth {depth:2d} leaf {leaf:2d}: build {tb:.2f}s nodes {len(tree.nodes)/1e6:.2f}M refs {len(tree.recs)/1e6:.2f}M "
-              f"| frame {best['frame']:.2f} ms (closest {best['closest']:.2f} shade {best['shade']:.2f}) {rays/best['frame']/1e3:.0f} Mrays/s "
+              f"| frame {best['frame']:.2f} ms (closest {best['closest']:.2f} shadow {best['shadow']:.2f} shade {best['shade']:.2f}) {rays/best['frame']/1e3:.0f} Mrays/s "
               f"| closest/ray: {nc/st['raysClosest']:.1f} nodes {tc/st['raysClosest']:.1f} tris; shadow/ray: {ns/max(st['raysShadow'],1):.1f} nodes {ts/max(st['raysShadow'],1):.1f} tris "
               f"| maxStack {st['maxStack']} spills {st['spillPushes']}", flush=True)
         tree.release()
