@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "librt_amd.so")
+# RT_AMD_LIB selects an alternative build of the same library (kernel tuning experiments)
+SO = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")
 _lib = None
 
 

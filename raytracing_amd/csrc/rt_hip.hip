@@ -40,7 +40,12 @@
 #include "rt_hip.h"
 
 #define RT_BLOCK      256
-#define RT_LDS_STACK  16
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK  12     // traversal stack entries per lane kept in LDS
+#endif
+#ifndef RT_WAVES
+#define RT_WAVES      6      // resident waves per SIMD the traversal kernels are compiled for
+#endif
 #define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
 
@@ -142,7 +147,13 @@ DEVI uint32_t wave_append( uint32_t *counter, bool want )
 	return base + lanes_below( m );
 }
 
-struct StackRef { uint2 *lds; uint2 *spill; uint32_t stride; };
+// LDS part of the traversal stacks of one workgroup: entry k of thread t sits
+// at [k * RT_BLOCK + t], so a wave's push or pop touches 64 consecutive
+// 8-byte words (no bank conflicts).  File scope keeps every access in the
+// LDS address space.
+__shared__ uint2 g_lds_stack[RT_LDS_STACK * RT_BLOCK];
+
+struct StackRef { uint2 *spill; uint32_t stride; };
 
 struct Tally { uint32_t nodes, tris, spills, maxSp; };
 
@@ -151,7 +162,7 @@ DEVI void stack_push( const StackRef &s, int sp, uint32_t node, float tFar, Tall
 {
 	uint2 v = make_uint2( node, __float_as_uint( tFar ) );
 	if ( sp < RT_LDS_STACK )
-		s.lds[sp * RT_BLOCK] = v;
+		g_lds_stack[sp * RT_BLOCK + threadIdx.x] = v;
 	else
 	{
 		s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride] = v;
@@ -161,7 +172,12 @@ DEVI void stack_push( const StackRef &s, int sp, uint32_t node, float tFar, Tall
 }
 DEVI uint2 stack_pop( const StackRef &s, int sp )
 {
-	return ( sp < RT_LDS_STACK ) ? s.lds[sp * RT_BLOCK] : s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride];
+	uint2 v;
+	if ( sp < RT_LDS_STACK )
+		v = g_lds_stack[sp * RT_BLOCK + threadIdx.x];
+	else
+		v = s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride];
+	return v;
 }
 
 // ---------------------------------------------------------------------------
@@ -193,24 +209,22 @@ DEVI int ray_sphere( const Ray &r, float4 s, float &t )
 	return 1;
 }
 
-// :110-154 with e1 / e2 taken from the leaf record
-DEVI bool ray_tri( const Ray &r, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v )
+// :110-154 with e1 / e2 taken from the leaf record.  Same values and the same
+// accept / reject decisions as the reference's early-out form, evaluated
+// without branches: a wave runs the long path anyway as soon as one lane
+// needs it, and straight-line code lets the record loads be issued together.
+DEVI bool ray_tri( f3 src, f3 dest, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v )
 {
-	f3 p = cross3( r.dest, e2 );
+	f3 p = cross3( dest, e2 );
 	float det = dot3( e1, p );
-	if ( det == 0.0f )
-		return false;
-	det = 1.0f / det;
-	f3 dist = sub3( r.src, v0 );
-	u = dot3( p, dist ) * det;
-	if ( ( u < 0.0f ) || ( u > 1.0f ) )
-		return false;
+	float inv = 1.0f / det;
+	f3 dist = sub3( src, v0 );
+	u = dot3( p, dist ) * inv;
 	f3 q = cross3( dist, e1 );
-	v = dot3( q, r.dest ) * det;
-	if ( ( v < 0.0f ) || ( v + u > 1.0f ) )
-		return false;
-	t = dot3( q, e2 ) * det;
-	return t > 0.0f;
+	v = dot3( q, dest ) * inv;
+	t = dot3( q, e2 ) * inv;
+	bool reject = ( det == 0.0f ) | ( u < 0.0f ) | ( u > 1.0f ) | ( v < 0.0f ) | ( v + u > 1.0f );
+	return !reject & ( t > 0.0f );
 }
 
 // :156-200
@@ -231,16 +245,22 @@ DEVI bool box_ray( const DevScene &S, const Ray &r, float &tNear, float &tFar )
 	return true;
 }
 
-DEVI void load_rec( const float4 *recs, uint32_t i, f3 &v0, f3 &e1, f3 &e2, uint32_t &tri, uint32_t &mat )
+// one 48-byte leaf record as three 16-byte loads
+struct Rec { float4 a, b, c; };
+DEVI Rec load_rec( const float4 *recs, uint32_t i )
 {
 	const float4 *p = recs + 3u * (size_t) i;
-	float4 a = p[0], b = p[1], c = p[2];
-	v0 = F3( a.x, a.y, a.z );
-	e1 = F3( a.w, b.x, b.y );
-	e2 = F3( b.z, b.w, c.x );
-	tri = __float_as_uint( c.y );
-	mat = __float_as_uint( c.z );
+	Rec r;
+	r.a = p[0];
+	r.b = p[1];
+	r.c = p[2];
+	return r;
 }
+DEVI f3 rec_v0( const Rec &r ) { return F3( r.a.x, r.a.y, r.a.z ); }
+DEVI f3 rec_e1( const Rec &r ) { return F3( r.a.w, r.b.x, r.b.y ); }
+DEVI f3 rec_e2( const Rec &r ) { return F3( r.b.z, r.b.w, r.c.x ); }
+DEVI uint32_t rec_tri( const Rec &r ) { return __float_as_uint( r.c.y ); }
+DEVI uint32_t rec_mat( const Rec &r ) { return __float_as_uint( r.c.z ); }
 
 // component `axis` of a vector held in registers.  Written on values, not on
 // struct members behind a reference: selecting between member loads gets
@@ -307,21 +327,23 @@ DEVI void kd_nearest( const DevScene &S, const Ray r, const StackRef &st, float 
 			n = S.nodes[cur];
 			if ( STATS ) ++tl.nodes;
 		}
-		uint32_t cnt = n.y >> 2;
+		const uint32_t cnt = n.y >> 2;
 		float lt = INFINITY;
+		// the record after the current one is always in flight (the array ends
+		// with one spare record, so the look-ahead never leaves the buffer)
+		Rec nx = load_rec( S.recs, n.x );
 		for ( uint32_t i = 0; i < cnt; ++i )
 		{
-			f3 v0, e1, e2;
-			uint32_t tri, mat;
+			const Rec rc = nx;
+			nx = load_rec( S.recs, n.x + i + 1u );
 			float t, u, v;
-			load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
 			if ( STATS ) ++tl.tris;
-			if ( ray_tri( r, v0, e1, e2, t, u, v ) && t < lt )
+			if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), t, u, v ) && t < lt )
 			{
 				lt = t;
 				minU = u;
 				minV = v;
-				prN = tri;
+				prN = rec_tri( rc );
 				nearestB = 1;
 			}
 		}
@@ -372,16 +394,16 @@ DEVI bool kd_alpha( const DevScene &S, const Ray r, const StackRef &st, float d,
 			n = S.nodes[cur];
 			if ( STATS ) ++tl.nodes;
 		}
-		uint32_t cnt = n.y >> 2;
+		const uint32_t cnt = n.y >> 2;
+		Rec nx = load_rec( S.recs, n.x );
 		for ( uint32_t i = 0; i < cnt; ++i )
 		{
-			f3 v0, e1, e2;
-			uint32_t tri, mat;
+			const Rec rc = nx;
+			nx = load_rec( S.recs, n.x + i + 1u );
 			float t, u, v;
-			load_rec( S.recs, n.x + i, v0, e1, e2, tri, mat );
 			if ( STATS ) ++tl.tris;
-			if ( ray_tri( r, v0, e1, e2, t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
-				alpha += S.mats[mat].color.a;
+			if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
+				alpha += S.mats[rec_mat( rc )].color.a;
 		}
 		// the caller clamps the sum to [0,1]: with non-negative opacities it
 		// cannot drop below 1 again, the rest of the ray is irrelevant
@@ -497,10 +519,9 @@ DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
 	atomicMax( &W.ctr->maxStack, (unsigned long long) tl.maxSp );
 }
 
-DEVI StackRef make_stack( uint2 *lds, const Work &W )
+DEVI StackRef make_stack( const Work &W )
 {
 	StackRef st;
-	st.lds = lds + threadIdx.x;
 	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
 	st.stride = W.spillStride;
 	return st;
@@ -521,10 +542,9 @@ DEVI bool next_chunk( uint32_t *head, unsigned long long total, uint32_t &first 
 // k_closest: closest-hit pass of one slot
 // ---------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__( RT_BLOCK ) void k_closest( DevScene S, Work W, int slot, int wantIds )
+__global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, Work W, int slot, int wantIds )
 {
-	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
-	const StackRef st = make_stack( s_stack, W );
+	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u };
 
 	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
@@ -606,10 +626,9 @@ DEVI void to_light( const DevScene &S, int o, f3 P, f3 &toLight, float &d )
 // carries the sphere sum keeps it when the ray misses the scene box, so the
 // sphere opacity is then counted twice, as in the reference.
 template <bool STATS>
-__global__ __launch_bounds__( RT_BLOCK ) void k_shadow( DevScene S, Work W, int slot )
+__global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Work W, int slot )
 {
-	__shared__ uint2 s_stack[RT_LDS_STACK * RT_BLOCK];
-	const StackRef st = make_stack( s_stack, W );
+	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u };
 
 	const uint32_t hits = W.ctr->hitCount[slot];
@@ -1069,6 +1088,9 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 	c->maxMatTree = maxMat;
 	HIPCHK( hipSetDevice( c->device ) );
 	if ( upload( c, c->nodes, nodes, nNodes * sizeof( rt_hip_kdnode ) ) ) return 1;
+	// one spare record: the leaf loop loads one record ahead
+	if ( ensure( c, c->recs, ( nRecs + 1 ) * sizeof( rt_hip_trirec ) ) ) return 1;
+	HIPCHK( hipMemsetAsync( (char *) c->recs.p + nRecs * sizeof( rt_hip_trirec ), 0, sizeof( rt_hip_trirec ), c->stream ) );
 	if ( upload( c, c->recs, recs, nRecs * sizeof( rt_hip_trirec ) ) ) return 1;
 	if ( upload( c, c->shade, shade, nTris * sizeof( rt_hip_trishade ) ) ) return 1;
 	c->nNodes = nNodes; c->nRecs = nRecs; c->nTris = nTris; c->treeDepth = depth;
