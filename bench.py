@@ -129,43 +129,45 @@ def main():
     fence()
 
     # ---- timed region: exactly K steps ------------------------------------
-    kms = {"closest": 0.0, "shade": 0.0, "fold": 0.0, "frame": 0.0}
-    launches = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(RT_HIP_TIMING)
     fence()
     elapsed = time.perf_counter() - t0
-    # per-kernel HIP-event times of the last timed step (events live on the
-    # stream the kernels run on); read after the timed region
-    ms, launches = r.kernel_times()
-    for k in kms:
-        kms[k] = ms[k]
-    st = r.stats()                      # ray counters of the last frame (deterministic per frame)
+    # per-kernel HIP-event times, averaged over the timed steps (the events are
+    # recorded on the stream the kernels run on); read after the timed region
+    kms, launches = r.kernel_times()
+    st = r.stats()                      # ray counters of the last frame (identical for every frame)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     cnt = torch.tensor([st["raysClosest"], st["raysShadow"], st["hits"]], dtype=torch.float64, device=dev)
-    kt = torch.tensor([kms["closest"], kms["shade"], kms["fold"], kms["frame"]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     rays_frame = float(cnt[0] + cnt[1])
 
-    # ---- roofline of the dominant kernel (outside the timed region) --------
+    # ---- roofline of the dominant kernel (counting pass, outside the timed region)
     r.render(RT_HIP_STATS, d_out=frame_local.data_ptr())
     r.sync()
     sst = r.stats()
     nodes_c = sst["nodeVisits"] - sst["nodeVisitsShadow"]
     tris_c = sst["triTests"] - sst["triTestsShadow"]
     primary = sc.w * rows
-    bytes_closest = algorithmic_bytes(nodes_c, tris_c, primary, 0)
-    bytes_shade = algorithmic_bytes(sst["nodeVisitsShadow"], sst["triTestsShadow"], 0, sst["hits"])
-    dominant = "closest" if kms["closest"] >= kms["shade"] else "shade"
-    dom_bytes = bytes_closest if dominant == "closest" else bytes_shade
-    dom_ms = kms[dominant]
+    kbytes = {
+        # closest-hit passes: nodes + triangle records of the closest-hit queries
+        "closest": 8 * nodes_c + 48 * tris_c,
+        # shadow passes: nodes + triangle records of the shadow queries
+        "shadow": 8 * sst["nodeVisitsShadow"] + 48 * sst["triTestsShadow"],
+        # shading passes: 128 B of shading data per shaded hit
+        "shade": 128 * sst["hits"],
+        "fold": 4 * primary,
+    }
+    dominant = max(("closest", "shadow", "shade"), key=lambda k: kms[k])
+    dom_bytes, dom_ms = kbytes[dominant], kms[dominant]
     n_launch = max(launches.get(dominant, 1), 1)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    frame_bytes = algorithmic_bytes(sst["nodeVisits"], sst["triTests"], primary, sst["hits"])
 
     out = None
     if rank == 0:
@@ -186,12 +188,14 @@ def main():
                                       f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "
                                       "rows gathered on rank 0 (RCCL)"},
             "kernel_ms_per_frame_rank0": {k: round(x, 4) for k, x in kms.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_closest" if dominant == "closest" else "k_shade",
+            "roofline": {"bound": "hbm", "kernel": "k_" + dominant,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "launches_per_frame": n_launch,
                          "algorithmic_bytes_per_launch": int(dom_bytes / n_launch),
                          "avg_launch_ms": round(dom_ms / n_launch, 4),
+                         "frame_algorithmic_bytes": int(frame_bytes),
+                         "frame_achieved_GBs": round(frame_bytes / (kms["frame"] * 1e-3) / 1e9, 2),
                          "per_ray": {"nodes": round(sst["nodeVisits"] / max(sst["raysClosest"] + sst["raysShadow"], 1), 2),
                                      "tri_tests": round(sst["triTests"] / max(sst["raysClosest"] + sst["raysShadow"], 1), 2)}},
         }

@@ -125,9 +125,11 @@ int  rt_hip_sync( rt_hip_ctx *c );
 int  rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host );        /* internal frame buffer -> host, synchronous */
 int  rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host );      /* after RT_HIP_HITIDS */
 int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
-/* after RT_HIP_TIMING: ms[0] = closest-hit passes, ms[1] = shadow passes,
- * ms[2] = shading passes, ms[3] = fold + store, ms[4] = whole frame;
- * launches[i] = launch counts */
+/* Per-frame kernel time in ms, averaged over the frames rendered with
+ * RT_HIP_TIMING since the previous call (at most the last 32): ms[0] =
+ * closest-hit passes, ms[1] = shadow passes, ms[2] = shading passes, ms[3] =
+ * fold + store, ms[4] = whole frame; launches[i] = launches per frame.
+ * Measured with HIP events on the stream the kernels run on. */
 int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );
 
 #ifdef __cplusplus

@@ -48,6 +48,7 @@
 #endif
 #define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
+#define RT_TIMED_FRAMES 32
 
 // ---------------------------------------------------------------------------
 // device-side data
@@ -933,9 +934,10 @@ struct rt_hip_ctx
 	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridShade = 0;
 	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
-	hipEvent_t ev[3 * RT_MAX_SLOTS + 3] = {};
-	bool haveEvents = false, timed = false;
-	int timedSlots = 0;
+	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
+	hipEvent_t ev[RT_TIMED_FRAMES][3 * RT_MAX_SLOTS + 3] = {};
+	bool haveEvents = false;
+	int timedSlots = 0, timedFrames = 0;
 	uint32_t validPixels = 0;
 };
 
@@ -1040,7 +1042,7 @@ void rt_hip_destroy( rt_hip_ctx *c )
 	for ( DevBuf *b : all )
 		if ( b->p ) (void) hipFree( b->p );
 	if ( c->haveEvents )
-		for ( auto &e : c->ev ) (void) hipEventDestroy( e );
+		for ( auto &f : c->ev ) for ( auto &e : f ) (void) hipEventDestroy( e );
 	if ( c->own ) (void) hipStreamDestroy( c->own );
 	delete c;
 }
@@ -1281,11 +1283,15 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 
 	if ( timing && !c->haveEvents )
 	{
-		for ( auto &e : c->ev ) HIPCHK( hipEventCreate( &e ) );
+		for ( auto &f : c->ev ) for ( auto &e : f ) HIPCHK( hipEventCreate( &e ) );
 		c->haveEvents = true;
 	}
-	c->timed = timing;
-	c->timedSlots = S.stackSize;
+	if ( timing && c->timedSlots != S.stackSize )
+	{
+		c->timedSlots = S.stackSize;
+		c->timedFrames = 0;
+	}
+	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
 	int evi = 0;
 
 	HIPCHK( hipMemsetAsync( c->ctr.p, 0, sizeof( Counters ), s ) );
@@ -1299,18 +1305,19 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
 		if ( k == 0 && want * (uint32_t) ( S.nLights > 0 ? S.nLights : 1 ) < (uint32_t) gw ) gw = (int) ( want ? want * ( S.nLights > 0 ? S.nLights : 1 ) : 1u );
 		if ( k == 0 && want < (uint32_t) gs ) gs = (int) ( want ? want : 1u );
-		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+		if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
 		if ( stats ) hipLaunchKernelGGL( k_closest<true>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
 		else hipLaunchKernelGGL( k_closest<false>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
-		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+		if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
 		if ( stats ) hipLaunchKernelGGL( k_shadow<true>, dim3( gw ), dim3( RT_BLOCK ), 0, s, S, W, k );
 		else hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, s, S, W, k );
-		if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+		if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
 		hipLaunchKernelGGL( k_shade, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
 	}
-	if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+	if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
 	hipLaunchKernelGGL( k_fold, dim3( ( W.npix + RT_BLOCK - 1 ) / RT_BLOCK ), dim3( RT_BLOCK ), 0, s, W, out, S.stackSize );
-	if ( timing ) HIPCHK( hipEventRecord( c->ev[evi++], s ) );
+	if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
+	if ( timing ) ++c->timedFrames;
 	HIPCHK( hipGetLastError() );
 	return 0;
 }
@@ -1368,25 +1375,32 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 {
 	if ( !c || !ms || !launches ) return fail( "rt_hip_kernel_times: bad arguments" );
-	if ( !c->timed ) return fail( "rt_hip_kernel_times: last render was not timed" );
+	if ( c->timedFrames == 0 ) return fail( "rt_hip_kernel_times: no frame was rendered with RT_HIP_TIMING since the last call" );
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	for ( int i = 0; i < 5; ++i ) ms[i] = 0.0f;
-	int n = c->timedSlots, e = 0;
-	for ( int k = 0; k < n; ++k )
+	const int n = c->timedSlots;
+	const int frames = c->timedFrames < RT_TIMED_FRAMES ? c->timedFrames : RT_TIMED_FRAMES;
+	for ( int f = 0; f < frames; ++f )
 	{
-		float t[3] = { 0.0f, 0.0f, 0.0f };
-		for ( int j = 0; j < 3; ++j )
-		{
-			HIPCHK( hipEventElapsedTime( &t[j], c->ev[e + j], c->ev[e + j + 1] ) );
-			ms[j] += t[j];
-		}
-		e += 3;
+		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
+		int e = 0;
+		float t = 0.0f;
+		for ( int k = 0; k < n; ++k )
+			for ( int j = 0; j < 3; ++j, ++e )
+			{
+				HIPCHK( hipEventElapsedTime( &t, ev[e], ev[e + 1] ) );
+				ms[j] += t;
+			}
+		HIPCHK( hipEventElapsedTime( &t, ev[e], ev[e + 1] ) );
+		ms[3] += t;
+		HIPCHK( hipEventElapsedTime( &t, ev[0], ev[e + 1] ) );
+		ms[4] += t;
 	}
-	HIPCHK( hipEventElapsedTime( &ms[3], c->ev[e], c->ev[e + 1] ) );
-	HIPCHK( hipEventElapsedTime( &ms[4], c->ev[0], c->ev[e + 1] ) );
+	for ( int i = 0; i < 5; ++i ) ms[i] /= (float) frames;
 	launches[0] = launches[1] = launches[2] = n;
 	launches[3] = 1;
 	launches[4] = 3 * n + 1;
+	c->timedFrames = 0;
 	return 0;
 }
