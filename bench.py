@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 # kd-tree of the benchmark: the reference's split rule with its two limits made
 # run-time parameters (the reference's fixed depth 10 leaves ~2000 triangles
 # per leaf on this scene)
-TREE_DEPTH, TREE_LEAF = 28, 16
+TREE_DEPTH, TREE_LEAF = 28, 7
 
 WORKLOADS = {
     "config3": dict(make=scenes.config3, text="1M-triangle displaced sphere + floor, 3840x2160, "

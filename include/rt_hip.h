@@ -66,6 +66,10 @@ typedef struct _rt_hip_stats
 	uint64_t maxStack;      /* deepest traversal stack seen (STATS)        */
 	uint64_t nodeVisitsShadow;  /* part of nodeVisits spent in shadow queries (STATS) */
 	uint64_t triTestsShadow;    /* part of triTests spent in shadow queries   (STATS) */
+	/* lane-slots: 64 per wave-level iteration of the descend / leaf loop, so
+	 * e.g. (nodeVisits - nodeVisitsShadow) / nodeSlots is the fraction of
+	 * lanes doing useful work in the closest-hit descend loop (STATS) */
+	uint64_t nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;
 } rt_hip_stats;
 
 /* rt_hip_render flags */

@@ -31,6 +31,24 @@ typedef struct _rt_kdtree_flat
 	int depth;                /* deepest leaf, root = 0 */
 } rt_kdtree_flat;
 
+/* Builder options.  With sahStop = 0 and allAxes = 0 the tree is the
+ * reference's for the given limits.  The two extras (no reference
+ * counterpart) trade tree equality for traversal speed:
+ *   sahStop > 0  make a leaf when the best split costs >= sahStop x the cost
+ *                of not splitting (the reference always splits down to
+ *                maxPrims / maxDepth, which multiplies triangle references)
+ *   allAxes = 1  evaluate the 32 candidates on all three axes instead of the
+ *                longest one only */
+typedef struct _rt_kdtree_build_opts
+{
+	int   maxDepth, maxPrims, threads;
+	float sahStop;
+	int   allAxes;
+} rt_kdtree_build_opts;
+
+int  rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, rt_kdtree_flat *out );
+
 /* Returns 0 on success.  threads <= 0 picks the number of online CPUs
  * (capped at 16).  Triangle vertex indices must be global and < vertexCount. */
 int  rt_kdtree_build_flat( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,

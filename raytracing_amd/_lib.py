@@ -19,7 +19,8 @@ class RtError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("raysClosest", "raysShadow", "hits", "nodeVisits", "triTests",
-                 "spillPushes", "maxStack", "nodeVisitsShadow", "triTestsShadow")]
+                 "spillPushes", "maxStack", "nodeVisitsShadow", "triTestsShadow",
+                 "nodeSlots", "triSlots", "nodeSlotsShadow", "triSlotsShadow")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if not n.startswith("_")}
@@ -30,6 +31,11 @@ class FlatTree(C.Structure):      # rt_kdtree_flat
                 ("recs", C.c_void_p), ("nRecs", C.c_uint64),
                 ("shade", C.c_void_p), ("nTris", C.c_uint64),
                 ("bbox", C.c_float * 8), ("depth", C.c_int)]
+
+
+class BuildOpts(C.Structure):     # rt_kdtree_build_opts
+    _fields_ = [("maxDepth", C.c_int), ("maxPrims", C.c_int), ("threads", C.c_int),
+                ("sahStop", C.c_float), ("allAxes", C.c_int)]
 
 
 class RenderPipeStruct(C.Structure):   # rt_render_pipe
@@ -65,7 +71,7 @@ def lib():
                      "rt_hip_upload_spheres", "rt_hip_upload_lights", "rt_hip_set_camera",
                      "rt_hip_set_image", "rt_hip_set_tile", "rt_hip_local_rows", "rt_hip_set_param",
                      "rt_hip_render", "rt_hip_sync", "rt_hip_read_frame", "rt_hip_read_hit_ids",
-                     "rt_hip_get_stats", "rt_hip_kernel_times", "rt_kdtree_build_flat",
+                     "rt_hip_get_stats", "rt_hip_kernel_times", "rt_kdtree_build_flat", "rt_kdtree_build_flat_ex",
                      "rt_kdtree_flat_expand", "rt_kdtree_flatten", "rt_hip_device_count"):
             getattr(L, name).restype = C.c_int
         _lib = L

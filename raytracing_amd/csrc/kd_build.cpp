@@ -66,7 +66,8 @@ inline void child_boxes( const rt_box &b, int ax, float sep, rt_box &l, rt_box &
 // Candidate i is sep_i = min + i * delta; NL_i = #(mn < sep_i), NR_i = #(mx > sep_i);
 // the winner is the lowest i with the strictly smallest cost.
 template <class Get>
-void sah_sweep( uint64_t n, int ax, const rt_box &box, Get get, uint64_t &cntL, uint64_t &cntR, float &outSep )
+void sah_sweep( uint64_t n, int ax, const rt_box &box, Get get, uint64_t &cntL, uint64_t &cntR, float &outSep,
+	float *bestCost = nullptr, float *leafCost = nullptr )
 {
 	const float c = box_c( box, ax ), e = box_e( box, ax );
 	const float mn = c - e, mx = c + e;
@@ -142,6 +143,9 @@ void sah_sweep( uint64_t n, int ax, const rt_box &box, Get get, uint64_t &cntL, 
 			cntR = R[i];
 		}
 	}
+	if ( bestCost ) *bestCost = best;
+	// cost of keeping all n triangles in this box, in the same units
+	if ( leafCost ) *leafCost = ( area + ( mx - mn ) * ( eA + eB ) ) * n;
 }
 
 // ---------------------------------------------------------------------------
@@ -174,6 +178,8 @@ struct Builder
 {
 	const float *tmin[3], *tmax[3];
 	int maxDepth, maxPrims;
+	float sahStop = 0.0f;      // > 0: leaf when bestCost >= sahStop * leafCost (not in the reference)
+	int allAxes = 0;           // 1: try all three axes, keep the cheapest (not in the reference)
 	Pool pool;
 	size_t spawnThreshold = 2048;
 
@@ -186,12 +192,35 @@ struct Builder
 			node->prims.swap( prims );
 			return;
 		}
-		const int ax = split_axis( box );
-		const float *mnA = tmin[ax], *mxA = tmax[ax];
+		int ax = split_axis( box );
 		uint64_t cl = 0, cr = 0;
-		float sep = 0.0f;
+		float sep = 0.0f, best = 0.0f, leafCost = 0.0f;
 		const uint32_t *pp = prims.data();
-		sah_sweep( n, ax, box, [&]( uint64_t j, float &a, float &b ) { a = mnA[pp[j]]; b = mxA[pp[j]]; }, cl, cr, sep );
+		{
+			const float *mnA = tmin[ax], *mxA = tmax[ax];
+			sah_sweep( n, ax, box, [&]( uint64_t j, float &a, float &b ) { a = mnA[pp[j]]; b = mxA[pp[j]]; }, cl, cr, sep, &best, &leafCost );
+		}
+		if ( allAxes )
+			for ( int a2 = 0; a2 < 3; ++a2 )
+			{
+				if ( a2 == split_axis( box ) )
+					continue;
+				const float *mnB = tmin[a2], *mxB = tmax[a2];
+				uint64_t l2 = 0, r2 = 0;
+				float s2 = 0.0f, b2 = 0.0f;
+				sah_sweep( n, a2, box, [&]( uint64_t j, float &a, float &b ) { a = mnB[pp[j]]; b = mxB[pp[j]]; }, l2, r2, s2, &b2 );
+				if ( b2 < best )
+				{
+					best = b2; ax = a2; cl = l2; cr = r2; sep = s2;
+				}
+			}
+		if ( sahStop > 0.0f && best >= sahStop * leafCost )
+		{
+			node->leaf = true;
+			node->prims.swap( prims );
+			return;
+		}
+		const float *mnA = tmin[ax], *mxA = tmax[ax];
 
 		std::vector<uint32_t> pl, pr;
 		pl.reserve( cl );
@@ -380,6 +409,21 @@ int pick_threads( int threads )
 extern "C" int rt_kdtree_build_flat( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, int maxDepth, int maxPrims, int threads, rt_kdtree_flat *out )
 {
+	rt_kdtree_build_opts o;
+	memset( &o, 0, sizeof( o ) );
+	o.maxDepth = maxDepth;
+	o.maxPrims = maxPrims;
+	o.threads = threads;
+	return rt_kdtree_build_flat_ex( verts, tris, vertexCount, trianglesCount, &o, out );
+}
+
+extern "C" int rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, rt_kdtree_flat *out )
+{
+	if ( !opts )
+		return 1;
+	const int maxDepth = opts->maxDepth, maxPrims = opts->maxPrims;
+	int threads = opts->threads;
 	if ( !out || ( vertexCount && !verts ) || ( trianglesCount && !tris ) )
 		return 1;
 	if ( trianglesCount >= ( 1ull << 30 ) || maxDepth < 0 || maxDepth > RT_HIP_MAX_TREE_DEPTH || maxPrims < 1 )
@@ -422,6 +466,8 @@ extern "C" int rt_kdtree_build_flat( const rt_vertex *verts, const rt_triangle *
 	}
 	b.maxDepth = maxDepth;
 	b.maxPrims = maxPrims;
+	b.sahStop = opts->sahStop;
+	b.allAxes = opts->allAxes;
 
 	BNode *root = new BNode();
 	{

@@ -83,6 +83,7 @@ struct Counters
 	uint32_t headShadow[RT_MAX_SLOTS];    // chunk dispenser of k_shadow
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
+	unsigned long long nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;   // lane-slots spent (STATS)
 };
 
 struct Work
@@ -156,7 +157,10 @@ __shared__ uint2 g_lds_stack[RT_LDS_STACK * RT_BLOCK];
 
 struct StackRef { uint2 *spill; uint32_t stride; };
 
-struct Tally { uint32_t nodes, tris, spills, maxSp; };
+// nodeSlots / triSlots: 64 lane-slots per wave-level iteration of the descend /
+// leaf loop, shared among the lanes active in it (lane utilisation = nodes / nodeSlots)
+struct Tally { uint32_t nodes, tris, spills, maxSp; float nodeSlots, triSlots; };
+DEVI float lane_share() { return 64.0f / (float) __popcll( __ballot( 1 ) ); }
 
 template <bool STATS>
 DEVI void stack_push( const StackRef &s, int sp, uint32_t node, float tFar, Tally &tl )
@@ -296,130 +300,127 @@ DEVI uint32_t kd_inner( uint2 n, uint32_t cur, f3 src, f3 inv, f3 dest, float tN
 	return nearN;
 }
 
-// closest hit over the kd tree, CL/rt_funcs_primitives.cl:151-253 with the leaf
-// loop :74-111 inlined.  The per-leaf reset of the running distance while the
-// hit flag and the triangle id persist is the reference's behaviour.
-template <bool STATS>
-DEVI void kd_nearest( const DevScene &S, const Ray r, const StackRef &st, float &minT, float &minU,
-	float &minV, uint32_t &prN, int &nearestB, Tally &tl )
+// Per-lane traversal state.  A traversal is run in ROUNDS: descend to the next
+// leaf, scan it, then either finish or pop; between rounds the wave may hand
+// finished lanes a new ray (see the feeder below), which is what keeps lanes
+// busy when ray lengths differ.
+struct Trav
 {
 	float tNear, tFar;
-	minT = INFINITY;
-	if ( !box_ray( S, r, tNear, tFar ) )
-		return;
+	uint32_t cur;
+	int sp;
+	uint2 n;          // node `cur`, already loaded
+};
+
+// start of both queries (CL/rt_funcs_primitives.cl:160-163 / :289-291): scene
+// box test; false = the ray misses the box
+template <bool STATS>
+DEVI bool trav_begin( const DevScene &S, const Ray &r, Trav &t, Tally &tl )
+{
+	if ( !box_ray( S, r, t.tNear, t.tFar ) )
+		return false;
 	// A ray that starts inside the scene box has tNear < 0; the reference walks
 	// the cells behind the origin too (its box test does not clamp).  No hit
 	// can be accepted there (t > 0 is required and a leaf only confirms hits
 	// before its own exit distance), so start at the origin instead.
-	if ( tNear < 0.0f )
-		tNear = 0.0f;
-	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	uint32_t cur = 0;
-	int sp = 0;
-	uint2 n = S.nodes[0];
+	if ( t.tNear < 0.0f )
+		t.tNear = 0.0f;
+	t.cur = 0u;
+	t.sp = 0;
+	t.n = S.nodes[0];
 	if ( STATS ) ++tl.nodes;
-	for ( ;; )
+	return true;
+}
+
+// descend until `t.n` is a leaf; the whole wave stays in this tight loop until
+// every active lane has reached one, so the leaf scans run together
+template <bool STATS>
+DEVI void trav_descend( const DevScene &S, f3 src, f3 inv, f3 dest, const StackRef &st, Trav &t, Tally &tl )
+{
+	while ( ( t.n.y & 3u ) != 3u )
 	{
-		// descend to the next leaf; the whole wave stays in this tight loop
-		// until every lane has reached one, so the leaf scans run together
-		while ( ( n.y & 3u ) != 3u )
-		{
-			cur = kd_inner<STATS>( n, cur, src, inv, dest, tNear, tFar, st, sp, tl );
-			n = S.nodes[cur];
-			if ( STATS ) ++tl.nodes;
-		}
-		const uint32_t cnt = n.y >> 2;
-		float lt = INFINITY;
-		// the record after the current one is always in flight (the array ends
-		// with one spare record, so the look-ahead never leaves the buffer)
-		Rec nx = load_rec( S.recs, n.x );
-		for ( uint32_t i = 0; i < cnt; ++i )
-		{
-			const Rec rc = nx;
-			nx = load_rec( S.recs, n.x + i + 1u );
-			float t, u, v;
-			if ( STATS ) ++tl.tris;
-			if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), t, u, v ) && t < lt )
-			{
-				lt = t;
-				minU = u;
-				minV = v;
-				prN = rec_tri( rc );
-				nearestB = 1;
-			}
-		}
-		minT = lt;
-		if ( nearestB && ( minT < tFar ) )
-			return;
-		if ( !sp )
-			return;
-		--sp;
-		uint2 e = stack_pop( st, sp );
-		cur = e.x;
-		tNear = tFar;
-		tFar = __uint_as_float( e.y );
-		n = S.nodes[cur];
-		if ( STATS ) ++tl.nodes;
+		t.cur = kd_inner<STATS>( t.n, t.cur, src, inv, dest, t.tNear, t.tFar, st, t.sp, tl );
+		t.n = S.nodes[t.cur];
+		if ( STATS ) { ++tl.nodes; tl.nodeSlots += lane_share(); }
 	}
 }
 
-// shadow query: sum of the opacities of every triangle hit before the light,
-// CL/rt_funcs_primitives.cl:278-379 + :256-276.  Returns false (alpha
-// untouched) when the ray misses the scene box.
+// leave the current leaf: false = stack empty (traversal over)
 template <bool STATS>
-DEVI bool kd_alpha( const DevScene &S, const Ray r, const StackRef &st, float d, float &alpha, Tally &tl )
+DEVI bool trav_pop( const DevScene &S, const StackRef &st, Trav &t, Tally &tl )
 {
-	float tNear, tFar;
-	if ( !box_ray( S, r, tNear, tFar ) )
+	if ( !t.sp )
 		return false;
-	alpha = 0.0f;
-	// Only hits with tNear < t < tFar of their leaf AND t < d count, so the part
-	// of the ray beyond the light cannot contribute: walk [tNear, min(tFar, d)].
-	// Leaves keep the same split distances, hence the same hits are counted.
-	if ( d < tFar )
-		tFar = d;
-	if ( tNear < 0.0f )          // cells behind the origin hold no countable hit (t > 0)
-		tNear = 0.0f;
-	if ( !( tNear < tFar ) )
-		return true;
-	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	uint32_t cur = 0;
-	int sp = 0;
-	uint2 n = S.nodes[0];
+	--t.sp;
+	uint2 e = stack_pop( st, t.sp );
+	t.cur = e.x;
+	t.tNear = t.tFar;
+	t.tFar = __uint_as_float( e.y );
+	t.n = S.nodes[t.cur];
 	if ( STATS ) ++tl.nodes;
-	for ( ;; )
+	return true;
+}
+
+struct NearHit { float minT, minU, minV; uint32_t prN; int nearestB; };
+
+// One round of the closest-hit query, CL/rt_funcs_primitives.cl:165-252 with the
+// leaf loop :74-111 inlined; true = finished.  The per-leaf reset of the
+// running distance while the hit flag and the triangle id persist is the
+// reference's behaviour.
+template <bool STATS>
+DEVI bool nearest_round( const DevScene &S, const Ray &r, const StackRef &st, Trav &t, NearHit &h, Tally &tl )
+{
+	const f3 src = r.src, inv = r.inv, dest = r.dest;
+	trav_descend<STATS>( S, src, inv, dest, st, t, tl );
+	const uint32_t cnt = t.n.y >> 2;
+	float lt = INFINITY;
+	// the record after the current one is always in flight (the array ends
+	// with one spare record, so the look-ahead never leaves the buffer)
+	Rec nx = load_rec( S.recs, t.n.x );
+	for ( uint32_t i = 0; i < cnt; ++i )
 	{
-		while ( ( n.y & 3u ) != 3u )
+		const Rec rc = nx;
+		nx = load_rec( S.recs, t.n.x + i + 1u );
+		float tt, u, v;
+		if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
+		if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), tt, u, v ) && tt < lt )
 		{
-			cur = kd_inner<STATS>( n, cur, src, inv, dest, tNear, tFar, st, sp, tl );
-			n = S.nodes[cur];
-			if ( STATS ) ++tl.nodes;
+			lt = tt;
+			h.minU = u;
+			h.minV = v;
+			h.prN = rec_tri( rc );
+			h.nearestB = 1;
 		}
-		const uint32_t cnt = n.y >> 2;
-		Rec nx = load_rec( S.recs, n.x );
-		for ( uint32_t i = 0; i < cnt; ++i )
-		{
-			const Rec rc = nx;
-			nx = load_rec( S.recs, n.x + i + 1u );
-			float t, u, v;
-			if ( STATS ) ++tl.tris;
-			if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), t, u, v ) && ( t < d ) && ( t < tFar ) && ( t > tNear ) )
-				alpha += S.mats[rec_mat( rc )].color.a;
-		}
-		// the caller clamps the sum to [0,1]: with non-negative opacities it
-		// cannot drop below 1 again, the rest of the ray is irrelevant
-		if ( S.alphaMonotone && alpha >= 1.0f )
-			return true;
-		if ( !sp )
-			return true;
-		--sp;
-		uint2 e = stack_pop( st, sp );
-		cur = e.x;
-		tNear = tFar;
-		tFar = __uint_as_float( e.y );
-		n = S.nodes[cur];
-		if ( STATS ) ++tl.nodes;
 	}
+	h.minT = lt;
+	if ( h.nearestB && ( h.minT < t.tFar ) )
+		return true;
+	return !trav_pop<STATS>( S, st, t, tl );
+}
+
+// One round of the shadow query: sum of the opacities of every triangle hit
+// before the light, CL/rt_funcs_primitives.cl:295-378 + :256-276; true = finished.
+template <bool STATS>
+DEVI bool alpha_round( const DevScene &S, const Ray &r, const StackRef &st, Trav &t, float d, float &alpha, Tally &tl )
+{
+	const f3 src = r.src, inv = r.inv, dest = r.dest;
+	trav_descend<STATS>( S, src, inv, dest, st, t, tl );
+	const uint32_t cnt = t.n.y >> 2;
+	Rec nx = load_rec( S.recs, t.n.x );
+	for ( uint32_t i = 0; i < cnt; ++i )
+	{
+		const Rec rc = nx;
+		nx = load_rec( S.recs, t.n.x + i + 1u );
+		float tt, u, v;
+		if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
+		if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), tt, u, v ) && ( tt < d ) && ( tt < t.tFar ) && ( tt > t.tNear ) )
+			alpha += S.mats[rec_mat( rc )].color.a;
+	}
+	// the caller clamps the sum to [0,1]: with non-negative opacities it
+	// cannot drop below 1 again, the rest of the ray is irrelevant
+	if ( S.alphaMonotone && alpha >= 1.0f )
+		return true;
+	return !trav_pop<STATS>( S, st, t, tl );
 }
 
 // ---------------------------------------------------------------------------
@@ -511,6 +512,8 @@ DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
 {
 	atomicAdd( &W.ctr->nodeVisits, (unsigned long long) tl.nodes );
 	atomicAdd( &W.ctr->triTests, (unsigned long long) tl.tris );
+	atomicAdd( shadow ? &W.ctr->nodeSlotsShadow : &W.ctr->nodeSlots, (unsigned long long) tl.nodeSlots );
+	atomicAdd( shadow ? &W.ctr->triSlotsShadow : &W.ctr->triSlots, (unsigned long long) tl.triSlots );
 	if ( shadow )
 	{
 		atomicAdd( &W.ctr->nodeVisitsShadow, (unsigned long long) tl.nodes );
@@ -546,7 +549,7 @@ template <bool STATS>
 __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, Work W, int slot, int wantIds )
 {
 	const StackRef st = make_stack( W );
-	Tally tl = { 0u, 0u, 0u, 0u };
+	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
 	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
 	uint32_t first;
@@ -557,38 +560,45 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 		rh.pix = rh.pk = 0u;
 		const bool valid = load_ray( S, W, slot, e, count, rh );
 
-		float prMinT = INFINITY, trMinT = INFINITY, trU = 0.0f, trV = 0.0f;
-		uint32_t prN = 0u, trN = 0u;
-		int prB = 0, trB = 0;
+		float prMinT = INFINITY;
+		uint32_t prN = 0u;
+		int prB = 0;
+		NearHit h = { INFINITY, 0.0f, 0.0f, 0u, 0 };
 
 		if ( valid )
 		{
 			// all spheres, CL/rt_funcs_primitives.cl:381-416
 			for ( int i = 0; i < S.nSpheres; ++i )
 			{
-				float t;
-				int b = ray_sphere( rh.ray, S.spheres[i], t );
-				if ( b && t < prMinT )
+				float ts;
+				int b = ray_sphere( rh.ray, S.spheres[i], ts );
+				if ( b && ts < prMinT )
 				{
-					prMinT = t;
+					prMinT = ts;
 					prN = (uint32_t) i;
 					prB = b;
 				}
 			}
-			kd_nearest<STATS>( S, rh.ray, st, trMinT, trU, trV, trN, trB, tl );
+			// Neighbouring lanes carry neighbouring rays and walk the tree in step,
+			// so their node and record loads fall into the same cache lines.
+			// (Refilling finished lanes with fresh rays mid-flight was measured and
+			// halves the speed on this workload: it destroys exactly that locality.)
+			Trav t;
+			if ( trav_begin<STATS>( S, rh.ray, t, tl ) )
+				while ( !nearest_round<STATS>( S, rh.ray, st, t, h, tl ) ) {}
 		}
 
 		// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
 		// "flag set, no valid distance, no sphere" is shaded as a miss
-		const bool triHit = valid && ( trB || prB ) && ( trMinT < prMinT );
-		const bool sphHit = valid && ( trB || prB ) && !( trMinT < prMinT ) && prB;
+		const bool triHit = valid && ( h.nearestB || prB ) && ( h.minT < prMinT );
+		const bool sphHit = valid && ( h.nearestB || prB ) && !( h.minT < prMinT ) && prB;
 		const bool hit = triHit || sphHit;
 
 		const uint32_t hidx = wave_append( &W.ctr->hitCount[slot], hit );
 		if ( hit )
 		{
-			W.hitA[hidx] = make_float4( __uint_as_float( e ), triHit ? trMinT : prMinT, trU, trV );
-			W.hitB[hidx] = make_uint2( triHit ? trN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? trB : prB ) );
+			W.hitA[hidx] = make_float4( __uint_as_float( e ), triHit ? h.minT : prMinT, h.minU, h.minV );
+			W.hitB[hidx] = make_uint2( triHit ? h.prN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? h.nearestB : prB ) );
 		}
 		else if ( valid )
 		{
@@ -603,7 +613,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 			}
 		}
 		if ( slot == 0 && wantIds && valid )
-			W.hitId[rh.pix] = triHit ? (int32_t) trN : ( sphHit ? -2 - (int32_t) prN : -1 );
+			W.hitId[rh.pix] = triHit ? (int32_t) h.prN : ( sphHit ? -2 - (int32_t) prN : -1 );
 	}
 	if ( STATS )
 		flush_tally( W, tl, false );
@@ -630,19 +640,19 @@ template <bool STATS>
 __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Work W, int slot )
 {
 	const StackRef st = make_stack( W );
-	Tally tl = { 0u, 0u, 0u, 0u };
+	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
 	const uint32_t hits = W.ctr->hitCount[slot];
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
-	const unsigned long long total = (unsigned long long) hits * (unsigned long long) S.nLights;
+	const uint32_t total = hits * (uint32_t) S.nLights;      // < 2^31, checked by the host
 	uint32_t first;
 	while ( next_chunk( &W.ctr->headShadow[slot], total, first ) )
 	{
 		const uint32_t i = first + lane_id();
 		if ( i >= total )
 			continue;
-		const uint32_t o = i / hits, h = i - o * hits;
-		const float4 ha = W.hitA[h];
+		const uint32_t o = i / hits, hh = i - o * hits;
+		const float4 ha = W.hitA[hh];
 		RayHead rh;
 		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
 			continue;
@@ -658,15 +668,27 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 		float a = 0.0f;
 		for ( int k = 0; k < S.nSpheres; ++k )           // :418-448
 		{
-			float t;
-			int b = ray_sphere( sh, S.spheres[k], t );
-			if ( b && t < d )
+			float ts;
+			int b = ray_sphere( sh, S.spheres[k], ts );
+			if ( b && ts < d )
 				a += S.mats[S.sphereMat[k]].color.a;
 		}
-		float shadowed = clampf( a, 0.0f, 1.0f );
-		kd_alpha<STATS>( S, sh, st, d, a, tl );
-		shadowed += clampf( a, 0.0f, 1.0f );
-		W.shadow[(size_t) o * W.npix + h] = shadowed;
+		const float shadowed = clampf( a, 0.0f, 1.0f );
+		// :289-293: the triangle sum starts at zero only once the scene box is hit
+		Trav t;
+		if ( trav_begin<STATS>( S, sh, t, tl ) )
+		{
+			a = 0.0f;
+			// Only hits with tNear < t < tFar of their leaf AND t < d count, so the
+			// part of the ray beyond the light cannot contribute: walk
+			// [tNear, min(tFar, d)].  Leaves keep the same split distances, hence
+			// the same hits are counted.
+			if ( d < t.tFar )
+				t.tFar = d;
+			if ( t.tNear < t.tFar )
+				while ( !alpha_round<STATS>( S, sh, st, t, d, a, tl ) ) {}
+		}
+		W.shadow[(size_t) o * W.npix + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
 	if ( STATS )
 		flush_tally( W, tl, true );
@@ -1274,6 +1296,8 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	HIPCHK( hipSetDevice( c->device ) );
 	if ( c->S.nSpheres == 0 && !c->S.spheres ) { rt_sphere z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_spheres( c, &z, 0 ) ) return 1; }
 	if ( c->S.nLights == 0 && !c->S.lights ) { rt_point_light z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_lights( c, &z, 0 ) ) return 1; }
+	if ( (unsigned long long) c->S.w * c->S.localH * (unsigned long long) ( c->S.nLights > 0 ? c->S.nLights : 1 ) >= ( 1ull << 31 ) )
+		return fail( "rt_hip_render: pixels x lights exceeds the 31-bit work-item range" );
 	if ( ( c->workDirty || c->workLights != c->S.nLights ) && prepare_work( c ) ) return 1;
 	const bool stats = flags & RT_HIP_STATS, ids = flags & RT_HIP_HITIDS, timing = flags & RT_HIP_TIMING;
 	const DevScene &S = c->S;
@@ -1369,6 +1393,10 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	out->maxStack = h.maxStack;
 	out->nodeVisitsShadow = h.nodeVisitsShadow;
 	out->triTestsShadow = h.triTestsShadow;
+	out->nodeSlots = h.nodeSlots;
+	out->triSlots = h.triSlots;
+	out->nodeSlotsShadow = h.nodeSlotsShadow;
+	out->triSlotsShadow = h.triSlotsShadow;
 	return 0;
 }
 

@@ -51,13 +51,15 @@ class FlatTree:
         self.depth = struct.depth
 
     @classmethod
-    def build(cls, verts, tris, max_depth=10, max_prims=7, threads=0):
+    def build(cls, verts, tris, max_depth=10, max_prims=7, threads=0, sah_stop=0.0, all_axes=0):
+        """sah_stop / all_axes = 0 gives the reference's tree for the limits."""
+        from ._lib import BuildOpts
         verts = np.ascontiguousarray(verts, T.vertex)
         tris = np.ascontiguousarray(tris, T.triangle)
         s = _FlatTreeStruct()
-        rc = lib().rt_kdtree_build_flat(_p(verts), _p(tris), C.c_uint64(len(verts)),
-                                        C.c_uint64(len(tris)), C.c_int(max_depth), C.c_int(max_prims),
-                                        C.c_int(threads), C.byref(s))
+        o = BuildOpts(max_depth, max_prims, threads, sah_stop, all_axes)
+        rc = lib().rt_kdtree_build_flat_ex(_p(verts), _p(tris), C.c_uint64(len(verts)),
+                                           C.c_uint64(len(tris)), C.byref(o), C.byref(s))
         if rc:
             raise RtError(f"rt_kdtree_build_flat failed with code {rc}")
         return cls(s)

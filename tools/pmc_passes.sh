@@ -4,7 +4,7 @@
 set -u
 OUT=${1:-gpurun_out/pmc}
 shift || true
-ARGS=${*:-config3 28 16 2}
+ARGS=${*:-config3 28 7 2}
 export PYTHONPATH=.
 export TMPDIR=/tmp
 mkdir -p "$OUT"
@@ -20,4 +20,5 @@ run sq2 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ
 run tcc1 FETCH_SIZE TCC_HIT_sum || exit 1
 run tcc2 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum || exit 1
 run tcc3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum || exit 1
+run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum || exit 1
 echo all passes done

@@ -6,13 +6,16 @@ from raytracing_amd.pipe import HipRenderer, FlatTree, RT_HIP_STATS, RT_HIP_TIMI
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "config3"
-    combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]] or [(24, 7), (28, 7), (32, 7), (32, 16), (36, 12)]
+    combos = [tuple(float(x) for x in a.split(",")) for a in sys.argv[2:]] or [(24, 7), (28, 7), (32, 7), (32, 16), (36, 12)]
     sc = getattr(scenes, name)()
     v, t = sc.flatten()
     r = HipRenderer(0)
-    for depth, leaf in combos:
+    for combo in combos:
+        depth, leaf = int(combo[0]), int(combo[1])
+        stop = combo[2] if len(combo) > 2 else 0.0
+        axes = int(combo[3]) if len(combo) > 3 else 0
         t0 = time.time()
-        tree = FlatTree.build(v, t, depth, leaf)
+        tree = FlatTree.build(v, t, depth, leaf, 0, stop, axes)
         tb = time.time() - t0
         r.load_scene(sc, tree)
         best = None
@@ -27,10 +30,12 @@ def main():
         rays = st0["raysClosest"] + st0["raysShadow"]
         nc, ns = st["nodeVisits"] - st["nodeVisitsShadow"], st["nodeVisitsShadow"]
         tc, ts = st["triTests"] - st["triTestsShadow"], st["triTestsShadow"]
-        print(f"{name} depth {depth:2d} leaf {leaf:2d}: build {tb:.2f}s nodes {len(tree.nodes)/1e6:.2f}M refs {len(tree.recs)/1e6:.2f}M "
+        print(f"{name} depth {depth:2d} leaf {leaf:2d} stop {stop} axes {axes}: build {tb:.2f}s nodes {len(tree.nodes)/1e6:.2f}M refs {len(tree.recs)/1e6:.2f}M "
               f"| frame {best['frame']:.2f} ms (closest {best['closest']:.2f} shadow {best['shadow']:.2f} shade {best['shade']:.2f}) {rays/best['frame']/1e3:.0f} Mrays/s "
               f"| closest/ray: {nc/st['raysClosest']:.1f} nodes {tc/st['raysClosest']:.1f} tris; shadow/ray: {ns/max(st['raysShadow'],1):.1f} nodes {ts/max(st['raysShadow'],1):.1f} tris "
-              f"| maxStack {st['maxStack']} spills {st['spillPushes']}", flush=True)
+              f"| maxStack {st['maxStack']} spills {st['spillPushes']} "
+              f"| lane use closest: descend {nc/max(st['nodeSlots'],1):.2f} leaf {tc/max(st['triSlots'],1):.2f}; "
+              f"shadow: descend {ns/max(st['nodeSlotsShadow'],1):.2f} leaf {ts/max(st['triSlotsShadow'],1):.2f}", flush=True)
         tree.release()
     r.close()
 
