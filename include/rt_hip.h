@@ -38,10 +38,15 @@ typedef struct _rt_hip_kdnode { uint32_t a, b; } rt_hip_kdnode;
 /* 48-byte leaf triangle record: one per (leaf, triangle) reference, stored in
  * leaf order, so a leaf scan is one contiguous read with no indirection.
  * e1 = v1 - v0 and e2 = v2 - v0 are the fp32 differences the intersection
- * test would otherwise compute itself. */
+ * test would otherwise compute itself; nv0 = -v0 (exact), so that src - v0 is
+ * the single addition src + nv0.  The fields are interleaved in the pairs the
+ * kernel's two-wide fp32 instructions take as operands: a 16-byte load puts
+ * each pair into one aligned register pair. */
 typedef struct _rt_hip_trirec
 {
-	float    v0[3], e1[3], e2[3];
+	float    nv0x, e1x, nv0y, e1y;
+	float    nv0z, e1z, e2x, e2y;
+	float    e2z;
 	uint32_t tri;     /* index into the triangle / shading arrays */
 	uint32_t mat;     /* material slot */
 	uint32_t _pad;
@@ -70,6 +75,8 @@ typedef struct _rt_hip_stats
 	 * e.g. (nodeVisits - nodeVisitsShadow) / nodeSlots is the fraction of
 	 * lanes doing useful work in the closest-hit descend loop (STATS) */
 	uint64_t nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;
+	/* closest-hit queries and hits of each ray slot (slot 0 = primary rays) */
+	uint64_t slotRays[RT_STACK_SIZE_MAX], slotHits[RT_STACK_SIZE_MAX];
 } rt_hip_stats;
 
 /* rt_hip_render flags */
@@ -86,6 +93,8 @@ typedef struct _rt_hip_stats
 #define RT_PARAM_MAX_PRIMS_IN_NODE 3   /* kd leaf size, default 7 (render pipe only)      */
 #define RT_PARAM_BUILD_THREADS     4   /* host builder threads, 0 = automatic             */
 #define RT_PARAM_TREE_CACHE        5   /* 1 = reuse the tree while geometry is unchanged  */
+#define RT_PARAM_OVERLAP           6   /* 0 = run every pass on one stream, in order (default 1:
+                                          shadow + lighting passes on auxiliary streams)  */
 
 #define RT_HIP_MAX_TREE_DEPTH 64       /* deepest tree the traversal stack admits */
 
@@ -131,9 +140,11 @@ int  rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host );      /* after RT_HIP_H
 int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
 /* Per-frame kernel time in ms, averaged over the frames rendered with
  * RT_HIP_TIMING since the previous call (at most the last 32): ms[0] =
- * closest-hit passes, ms[1] = shadow passes, ms[2] = shading passes, ms[3] =
- * fold + store, ms[4] = whole frame; launches[i] = launches per frame.
- * Measured with HIP events on the stream the kernels run on. */
+ * closest-hit passes, ms[1] = shadow passes, ms[2] = shading passes (spawn +
+ * lighting), ms[3] = fold + store, ms[4] = whole frame; launches[i] = launches
+ * per frame.  Measured with HIP events on the stream each kernel runs on.
+ * With RT_PARAM_OVERLAP = 1 passes share the chip, so ms[0..3] add up to more
+ * than ms[4]; set it to 0 to time every pass running alone. */
 int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );
 
 #ifdef __cplusplus

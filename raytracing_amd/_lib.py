@@ -20,10 +20,15 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("raysClosest", "raysShadow", "hits", "nodeVisits", "triTests",
                  "spillPushes", "maxStack", "nodeVisitsShadow", "triTestsShadow",
-                 "nodeSlots", "triSlots", "nodeSlotsShadow", "triSlotsShadow")]
+                 "nodeSlots", "triSlots", "nodeSlotsShadow", "triSlotsShadow")] + [
+                ("slotRays", C.c_uint64 * 8), ("slotHits", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if not n.startswith("_")}
+        d = {}
+        for n, t in self._fields_:
+            v = getattr(self, n)
+            d[n] = int(v) if t is C.c_uint64 else [int(x) for x in v]
+        return d
 
 
 class FlatTree(C.Structure):      # rt_kdtree_flat

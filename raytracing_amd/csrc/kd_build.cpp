@@ -354,9 +354,9 @@ void fill_records( const rt_vertex *verts, const rt_triangle *tris, uint64_t nTr
 			const rt_triangle &t = tris[order[i]];
 			const rt_vector3 &p0 = verts[t.pV0].pos, &p1 = verts[t.pV1].pos, &p2 = verts[t.pV2].pos;
 			rt_hip_trirec &r = recs[i];
-			r.v0[0] = p0.x; r.v0[1] = p0.y; r.v0[2] = p0.z;
-			r.e1[0] = p1.x - p0.x; r.e1[1] = p1.y - p0.y; r.e1[2] = p1.z - p0.z;
-			r.e2[0] = p2.x - p0.x; r.e2[1] = p2.y - p0.y; r.e2[2] = p2.z - p0.z;
+			r.nv0x = -p0.x; r.nv0y = -p0.y; r.nv0z = -p0.z;
+			r.e1x = p1.x - p0.x; r.e1y = p1.y - p0.y; r.e1z = p1.z - p0.z;
+			r.e2x = p2.x - p0.x; r.e2y = p2.y - p0.y; r.e2z = p2.z - p0.z;
 			r.tri = order[i];
 			r.mat = (uint32_t) t.mat;
 			r._pad = 0;

@@ -18,11 +18,20 @@ from ._lib import RenderPipeStruct, RtError, Stats, check, lib
 
 RT_HIP_STATS, RT_HIP_HITIDS, RT_HIP_TIMING = 1, 2, 4
 (RT_PARAM_STACK_SIZE, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
- RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE) = 1, 2, 3, 4, 5
+ RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE, RT_PARAM_OVERLAP) = 1, 2, 3, 4, 5, 6
 
 kdnode = np.dtype([("a", "<u4"), ("b", "<u4")])
-trirec = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3),
-                   ("tri", "<u4"), ("mat", "<u4"), ("_pad", "<u4")])
+trirec = np.dtype([("nv0x", "<f4"), ("e1x", "<f4"), ("nv0y", "<f4"), ("e1y", "<f4"),
+                   ("nv0z", "<f4"), ("e1z", "<f4"), ("e2x", "<f4"), ("e2y", "<f4"),
+                   ("e2z", "<f4"), ("tri", "<u4"), ("mat", "<u4"), ("_pad", "<u4")])
+
+
+def rec_vectors(recs):
+    """(v0, e1, e2) of leaf records as [n, 3] float32 arrays."""
+    v0 = -np.stack([recs["nv0x"], recs["nv0y"], recs["nv0z"]], axis=1)
+    e1 = np.stack([recs["e1x"], recs["e1y"], recs["e1z"]], axis=1)
+    e2 = np.stack([recs["e2x"], recs["e2y"], recs["e2z"]], axis=1)
+    return v0, e1, e2
 trishade = np.dtype([("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
                      ("mat", "<u4"), ("_pad", "<u4", 2)])
 

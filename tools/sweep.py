@@ -1,8 +1,8 @@
 """Development helper: time the benchmark frame for several kd-tree limits."""
-import sys, time
+import os, sys, time
 import numpy as np
 from raytracing_amd import scenes
-from raytracing_amd.pipe import HipRenderer, FlatTree, RT_HIP_STATS, RT_HIP_TIMING
+from raytracing_amd.pipe import HipRenderer, FlatTree, RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_OVERLAP
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "config3"
@@ -18,6 +18,8 @@ def main():
         tree = FlatTree.build(v, t, depth, leaf, 0, stop, axes)
         tb = time.time() - t0
         r.load_scene(sc, tree)
+        if os.environ.get("RT_OVERLAP") is not None:
+            r.set_param(RT_PARAM_OVERLAP, int(os.environ["RT_OVERLAP"]))
         best = None
         for _ in range(4):
             r.render(RT_HIP_TIMING)
@@ -36,6 +38,7 @@ def main():
               f"| maxStack {st['maxStack']} spills {st['spillPushes']} "
               f"| lane use closest: descend {nc/max(st['nodeSlots'],1):.2f} leaf {tc/max(st['triSlots'],1):.2f}; "
               f"shadow: descend {ns/max(st['nodeSlotsShadow'],1):.2f} leaf {ts/max(st['triSlotsShadow'],1):.2f}", flush=True)
+        print("   slot rays", st["slotRays"][:sc.stack_size], "hits", st["slotHits"][:sc.stack_size], flush=True)
         tree.release()
     r.close()
 
