@@ -214,20 +214,91 @@ DEVI int ray_sphere( const Ray &r, float4 s, float &t )
 	return 1;
 }
 
-// :110-154 with e1 / e2 taken from the leaf record.  Same values and the same
-// accept / reject decisions as the reference's early-out form, evaluated
-// without branches: a wave runs the long path anyway as soon as one lane
-// needs it, and straight-line code lets the record loads be issued together.
-DEVI bool ray_tri( f3 src, f3 dest, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v )
+// Two-wide fp32 values: operations on them compile to the packed fp32
+// instructions, which round each half exactly like the scalar instruction, so
+// packing changes instruction counts, not results.
+typedef float v2f __attribute__(( ext_vector_type( 2 ) ));
+DEVI v2f V2( float x, float y ) { v2f r = { x, y }; return r; }
+DEVI v2f splat( float x ) { v2f r = { x, x }; return r; }
+DEVI v2f swap2( v2f a ) { return __builtin_shufflevector( a, a, 1, 0 ); }
+
+// per-ray constants of the triangle test in the register pairs it consumes.
+// Signs are folded into the constants (a * -b == -(a * b) and x + -y == x - y
+// hold exactly), so that every difference of two products below is the plain
+// sum of one register pair with another.
+struct TriRay
 {
-	f3 p = cross3( dest, e2 );
-	float det = dot3( e1, p );
-	float inv = 1.0f / det;
-	f3 dist = sub3( src, v0 );
-	u = dot3( p, dist ) * inv;
-	f3 q = cross3( dist, e1 );
-	v = dot3( q, dest ) * inv;
-	t = dot3( q, e2 ) * inv;
+	v2f dA;               // (-dest.x, dest.y)
+	v2f dZ;               // ( dest.z, -dest.z)
+	v2f sx, sy, sz;       // (src.c, -0): adding (-v0.c, e1.c) yields (src.c - v0.c, e1.c)
+};
+DEVI TriRay tri_ray( f3 src, f3 dest )
+{
+	TriRay r;
+	r.dA = V2( -dest.x, dest.y );
+	r.dZ = V2( dest.z, -dest.z );
+	r.sx = V2( src.x, -0.0f );
+	r.sy = V2( src.y, -0.0f );
+	r.sz = V2( src.z, -0.0f );
+	return r;
+}
+// keeps a value in a vector register of its own (stops the compiler from
+// re-vectorising scalar results through extra moves)
+DEVI float own_reg( float x ) { asm( "" : "+v"( x ) ); return x; }
+
+// one 48-byte leaf record as three 16-byte loads
+struct Rec { float4 a, b, c; };
+DEVI Rec load_rec( const float4 *recs, uint32_t i )
+{
+	const float4 *p = recs + 3u * (size_t) i;
+	Rec r;
+	r.a = p[0];
+	r.b = p[1];
+	r.c = p[2];
+	return r;
+}
+DEVI uint32_t rec_tri( const Rec &r ) { return __float_as_uint( r.c.y ); }
+DEVI uint32_t rec_mat( const Rec &r ) { return __float_as_uint( r.c.z ); }
+
+// CL/rt_intersection.cl:110-154 with e1 / e2 taken from the leaf record.  Same
+// values and the same accept / reject decisions as the reference's early-out
+// form, evaluated without branches (a wave runs the long path anyway as soon
+// as one lane needs it, and straight-line code lets the record loads be issued
+// together) and two products at a time:
+//   p = dest x e2, dist = src - v0, q = dist x e1,
+//   det = e1.p, u = (p.dist)/det, v = (q.dest)/det, t = (q.e2)/det
+// Every product and every sum below is one of the reference's, rounded once
+// (x - y is also written x + (-y), which is the same operation).
+DEVI bool ray_tri( const TriRay &R, const Rec &rc, float &t, float &u, float &v )
+{
+	const v2f e2xy = V2( rc.b.z, rc.b.w );
+	const float e2z = rc.c.x;
+	// dest x e2
+	const v2f m1 = R.dA * splat( e2z );                  // (-dx*ez,  dy*ez)
+	const v2f m2 = R.dZ * e2xy;                          // ( dz*ex, -dz*ey)
+	const v2f m3 = R.dA * swap2( e2xy );                 // (-dx*ey,  dy*ex)
+	const v2f n = m2 + m1;                               // (p.y, p.x)
+	const float pz = -m3.x - m3.y;
+	// (dist.c, e1.c) per component
+	const v2f X = R.sx + V2( rc.a.x, rc.a.y );
+	const v2f Y = R.sy + V2( rc.a.z, rc.a.w );
+	const v2f Z = R.sz + V2( rc.b.x, rc.b.y );
+	// (p.dist, p.e1) = ((px*X + py*Y) + pz*Z)
+	const v2f ud = ( splat( n.y ) * X + splat( n.x ) * Y ) + splat( pz ) * Z;
+	const float det = ud.y;
+	const float inv = 1.0f / det;
+	// dist x e1
+	const v2f c1 = Y * swap2( Z );                       // (ty*e1z, e1y*tz)
+	const v2f c2 = Z * swap2( X );                       // (tz*e1x, e1z*tx)
+	const v2f c3 = X * swap2( Y );                       // (tx*e1y, e1x*ty)
+	const float qx = own_reg( c1.x - c1.y ), qy = own_reg( c2.x - c2.y ), qz = own_reg( c3.x - c3.y );
+	const v2f qxy = V2( qx, qy );
+	const v2f wd = qxy * R.dA, we = qxy * e2xy;          // (-qx*dx, qy*dy), (qx*ex, qy*ey)
+	const float vn = own_reg( -wd.x + wd.y ) + qz * R.dZ.x;
+	const float tn = own_reg( we.x + we.y ) + qz * e2z;
+	u = ud.x * inv;
+	v = vn * inv;
+	t = tn * inv;
 	bool reject = ( det == 0.0f ) | ( u < 0.0f ) | ( u > 1.0f ) | ( v < 0.0f ) | ( v + u > 1.0f );
 	return !reject & ( t > 0.0f );
 }
@@ -249,23 +320,6 @@ DEVI bool box_ray( const DevScene &S, const Ray &r, float &tNear, float &tFar )
 		return false;
 	return true;
 }
-
-// one 48-byte leaf record as three 16-byte loads
-struct Rec { float4 a, b, c; };
-DEVI Rec load_rec( const float4 *recs, uint32_t i )
-{
-	const float4 *p = recs + 3u * (size_t) i;
-	Rec r;
-	r.a = p[0];
-	r.b = p[1];
-	r.c = p[2];
-	return r;
-}
-DEVI f3 rec_v0( const Rec &r ) { return F3( r.a.x, r.a.y, r.a.z ); }
-DEVI f3 rec_e1( const Rec &r ) { return F3( r.a.w, r.b.x, r.b.y ); }
-DEVI f3 rec_e2( const Rec &r ) { return F3( r.b.z, r.b.w, r.c.x ); }
-DEVI uint32_t rec_tri( const Rec &r ) { return __float_as_uint( r.c.y ); }
-DEVI uint32_t rec_mat( const Rec &r ) { return __float_as_uint( r.c.z ); }
 
 // component `axis` of a vector held in registers.  Written on values, not on
 // struct members behind a reference: selecting between member loads gets
@@ -368,28 +422,42 @@ struct NearHit { float minT, minU, minV; uint32_t prN; int nearestB; };
 // running distance while the hit flag and the triangle id persist is the
 // reference's behaviour.
 template <bool STATS>
-DEVI bool nearest_round( const DevScene &S, const Ray &r, const StackRef &st, Trav &t, NearHit &h, Tally &tl )
+DEVI void nearest_tri( const TriRay &R, const Rec &rc, float &lt, NearHit &h, Tally &tl )
+{
+	float tt, u, v;
+	if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
+	if ( ray_tri( R, rc, tt, u, v ) && tt < lt )
+	{
+		lt = tt;
+		h.minU = u;
+		h.minV = v;
+		h.prN = rec_tri( rc );
+		h.nearestB = 1;
+	}
+}
+
+template <bool STATS>
+DEVI bool nearest_round( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, Trav &t, NearHit &h, Tally &tl )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	trav_descend<STATS>( S, src, inv, dest, st, t, tl );
-	const uint32_t cnt = t.n.y >> 2;
 	float lt = INFINITY;
-	// the record after the current one is always in flight (the array ends
-	// with one spare record, so the look-ahead never leaves the buffer)
-	Rec nx = load_rec( S.recs, t.n.x );
-	for ( uint32_t i = 0; i < cnt; ++i )
+	// Two records are kept in flight and take turns (no register copies); the
+	// array ends with one spare record, so the look-ahead load of the last
+	// triangle stays inside the buffer.
+	uint32_t i = t.n.x;
+	const uint32_t end = i + ( t.n.y >> 2 );
+	if ( i != end )
 	{
-		const Rec rc = nx;
-		nx = load_rec( S.recs, t.n.x + i + 1u );
-		float tt, u, v;
-		if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
-		if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), tt, u, v ) && tt < lt )
+		Rec r0 = load_rec( S.recs, i );
+		for ( ;; )
 		{
-			lt = tt;
-			h.minU = u;
-			h.minV = v;
-			h.prN = rec_tri( rc );
-			h.nearestB = 1;
+			Rec r1 = load_rec( S.recs, i + 1u );
+			nearest_tri<STATS>( R, r0, lt, h, tl );
+			if ( ++i == end ) break;
+			r0 = load_rec( S.recs, i + 1u );
+			nearest_tri<STATS>( R, r1, lt, h, tl );
+			if ( ++i == end ) break;
 		}
 	}
 	h.minT = lt;
@@ -401,20 +469,33 @@ DEVI bool nearest_round( const DevScene &S, const Ray &r, const StackRef &st, Tr
 // One round of the shadow query: sum of the opacities of every triangle hit
 // before the light, CL/rt_funcs_primitives.cl:295-378 + :256-276; true = finished.
 template <bool STATS>
-DEVI bool alpha_round( const DevScene &S, const Ray &r, const StackRef &st, Trav &t, float d, float &alpha, Tally &tl )
+DEVI void alpha_tri( const DevScene &S, const TriRay &R, const Rec &rc, const Trav &t, float d, float &alpha, Tally &tl )
+{
+	float tt, u, v;
+	if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
+	if ( ray_tri( R, rc, tt, u, v ) && ( tt < d ) && ( tt < t.tFar ) && ( tt > t.tNear ) )
+		alpha += S.mats[rec_mat( rc )].color.a;
+}
+
+template <bool STATS>
+DEVI bool alpha_round( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, Trav &t, float d, float &alpha, Tally &tl )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	trav_descend<STATS>( S, src, inv, dest, st, t, tl );
-	const uint32_t cnt = t.n.y >> 2;
-	Rec nx = load_rec( S.recs, t.n.x );
-	for ( uint32_t i = 0; i < cnt; ++i )
+	uint32_t i = t.n.x;
+	const uint32_t end = i + ( t.n.y >> 2 );
+	if ( i != end )
 	{
-		const Rec rc = nx;
-		nx = load_rec( S.recs, t.n.x + i + 1u );
-		float tt, u, v;
-		if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
-		if ( ray_tri( src, dest, rec_v0( rc ), rec_e1( rc ), rec_e2( rc ), tt, u, v ) && ( tt < d ) && ( tt < t.tFar ) && ( tt > t.tNear ) )
-			alpha += S.mats[rec_mat( rc )].color.a;
+		Rec r0 = load_rec( S.recs, i );
+		for ( ;; )
+		{
+			Rec r1 = load_rec( S.recs, i + 1u );
+			alpha_tri<STATS>( S, R, r0, t, d, alpha, tl );
+			if ( ++i == end ) break;
+			r0 = load_rec( S.recs, i + 1u );
+			alpha_tri<STATS>( S, R, r1, t, d, alpha, tl );
+			if ( ++i == end ) break;
+		}
 	}
 	// the caller clamps the sum to [0,1]: with non-negative opacities it
 	// cannot drop below 1 again, the rest of the ray is irrelevant
@@ -584,8 +665,9 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 			// (Refilling finished lanes with fresh rays mid-flight was measured and
 			// halves the speed on this workload: it destroys exactly that locality.)
 			Trav t;
+			const TriRay R = tri_ray( rh.ray.src, rh.ray.dest );
 			if ( trav_begin<STATS>( S, rh.ray, t, tl ) )
-				while ( !nearest_round<STATS>( S, rh.ray, st, t, h, tl ) ) {}
+				while ( !nearest_round<STATS>( S, rh.ray, R, st, t, h, tl ) ) {}
 		}
 
 		// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
@@ -686,7 +768,10 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 			if ( d < t.tFar )
 				t.tFar = d;
 			if ( t.tNear < t.tFar )
-				while ( !alpha_round<STATS>( S, sh, st, t, d, a, tl ) ) {}
+			{
+				const TriRay R = tri_ray( sh.src, sh.dest );
+				while ( !alpha_round<STATS>( S, sh, R, st, t, d, a, tl ) ) {}
+			}
 		}
 		W.shadow[(size_t) o * W.npix + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
@@ -1047,6 +1132,9 @@ rt_hip_ctx *rt_hip_create( int device )
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
 			occ = 1;
 		if ( occ > 8 ) occ = 8;
+#ifdef RT_OCC_CAP
+		if ( occ > RT_OCC_CAP ) occ = RT_OCC_CAP;
+#endif
 		*k.dst = occ * c->numCU;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
 	}
@@ -1397,6 +1485,11 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	out->triSlots = h.triSlots;
 	out->nodeSlotsShadow = h.nodeSlotsShadow;
 	out->triSlotsShadow = h.triSlotsShadow;
+	for ( int k = 0; k < RT_MAX_SLOTS; ++k )
+	{
+		out->slotRays[k] = k ? h.rayCount[k] : c->validPixels;
+		out->slotHits[k] = h.hitCount[k];
+	}
 	return 0;
 }
 
