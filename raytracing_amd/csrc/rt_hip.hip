@@ -8,11 +8,18 @@
 //                   misses finish their slot, hits are COMPACTED into a hit list
 //     k_shadow<k>   hit list k x lights -> one shadow traversal per item (lean
 //                   register state: only what the traversal needs)
-//     k_shade<k>    hit list k  -> hit point, normal, Phong terms; child rays are
-//                   appended (wave-aggregated atomics) to the ray lists of the
-//                   slots they occupy; no traversal, pure streaming
+//     k_spawn<k>    hit list k  -> hit point, normal; child rays are appended
+//                   (wave-aggregated atomics) to the ray lists of the slots they
+//                   occupy; no traversal, pure streaming
+//     k_light<k>    hit list k + shadow sums -> Phong terms, slot colour
 //   k_fold          per pixel: fold child colours into parents back to front,
 //                   clamp, truncate to 8-bit BGRA
+//
+// Only closest -> spawn -> closest of the next slot is a dependency chain; the
+// shadow and lighting passes of a slot hang off it.  The deep slots hold few
+// but very long rays (a few busy waves, the rest of the chip idle), so the
+// chain runs on the caller's stream and the shadow / lighting passes on two
+// auxiliary streams that fill the idle part of the chip.
 //
 // This is the reference's iterative ray tree (CL/rt_funcs_primitives.cl:584-728)
 // turned inside out: the reference walks the <= 6 slots of ONE pixel in a
@@ -49,6 +56,18 @@
 #define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
 #define RT_TIMED_FRAMES 32
+#ifndef RT_AUX_OCC
+#define RT_AUX_OCC    4      // blocks per CU of a shadow pass that runs beside the closest-hit chain
+#endif
+#ifndef RT_TRAV_GRAB
+#define RT_TRAV_GRAB   1u    // chunks a traversal wave takes per atomic
+#endif
+#ifndef RT_STREAM_GRAB
+#define RT_STREAM_GRAB 16u   // chunks a streaming wave takes per atomic (at most)
+#endif
+#ifndef RT_STREAM_OCC
+#define RT_STREAM_OCC 4      // blocks per CU of the streaming (non-traversal) passes
+#endif
 
 // ---------------------------------------------------------------------------
 // device-side data
@@ -74,13 +93,18 @@ struct DevScene
 	int alphaMonotone;        // every material opacity is >= 0: a shadow sum that reached 1 stays >= 1
 };
 
+// Every list counter sits in a cache line of its own: all waves of a launch
+// hammer two of them (chunk dispenser, append position), and atomics on one
+// line are executed one after the other by the L2 channel that owns it.
+struct alignas( 128 ) Ctr { uint32_t v; uint32_t pad[31]; };
 struct Counters
 {
-	uint32_t rayCount[RT_MAX_SLOTS];      // entries in ray list k (k >= 1)
-	uint32_t headClosest[RT_MAX_SLOTS];   // chunk dispenser of k_closest
-	uint32_t hitCount[RT_MAX_SLOTS];      // entries in the hit list of slot k
-	uint32_t headShade[RT_MAX_SLOTS];     // chunk dispenser of k_shade
-	uint32_t headShadow[RT_MAX_SLOTS];    // chunk dispenser of k_shadow
+	Ctr rayCount[RT_MAX_SLOTS];           // entries in ray list k (k >= 1)
+	Ctr headClosest[RT_MAX_SLOTS];        // chunk dispenser of k_closest
+	Ctr hitCount[RT_MAX_SLOTS];           // entries in the hit list of slot k
+	Ctr headSpawn[RT_MAX_SLOTS];          // chunk dispenser of k_spawn
+	Ctr headShade[RT_MAX_SLOTS];          // chunk dispenser of k_light
+	Ctr headShadow[RT_MAX_SLOTS];         // chunk dispenser of k_shadow
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
 	unsigned long long nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;   // lane-slots spent (STATS)
@@ -90,11 +114,14 @@ struct Work
 {
 	Counters *ctr;
 	float4 *rayA, *rayB, *rayC, *rayD;    // [(slot-1) * npix + entry]
+	// hit lists, one per slot ([slot * npix + hit]): the passes of different
+	// slots overlap in time
 	float4 *hitA;                         // (entry, t, u, v)
 	uint2  *hitB;                         // (id | sphere flag, b)
+	float4 *hitN;                         // (shading normal xyz, material slot), written by k_spawn
 	float4 *res;                          // [slot * npix + pix] (col rgb, parent slot)
 	float4 *fac;                          // [slot * npix + pix] weight of this slot in its parent
-	float  *shadow;                       // [light * npix + hit] summed shadow opacity
+	float  *shadow;                       // [(slot * nLights + light) * npix + hit] summed shadow opacity
 	uint32_t *stackPos;                   // last used slot of each pixel
 	int32_t *hitId;                       // optional primary hit ids
 	uint2  *spill;                        // traversal stack overflow
@@ -612,15 +639,41 @@ DEVI StackRef make_stack( const Work &W )
 	return st;
 }
 
-// every wave pulls 64-entry chunks until the list is exhausted
-DEVI bool next_chunk( uint32_t *head, unsigned long long total, uint32_t &first )
+// Work distribution: every wave pulls 64-entry chunks from a device counter
+// until the list is exhausted.  Atomics on ONE address are executed strictly
+// one after the other by the L2 (roughly 12 ns each on this chip), which at
+// one atomic per chunk bounds a launch from below by chunks x 12 ns: more
+// than the work itself for the streaming passes.  Those take several chunks
+// per atomic, many while the list is long and one at a time near its end
+// (guided self-scheduling).  The traversal passes take one chunk at a time:
+// their chunks are long enough, and measured, waves that walk through
+// consecutive chunks on their own are slower (2 chunks +3 %, 8 chunks +27 %).
+// (Narrower chunks for short lists were measured too: the long rays of the
+// deep slots are not shortened by them and the extra waves cost more than
+// they save.)
+struct Grab { uint32_t next, end; };
+DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_t &first, uint32_t maxGrab )
 {
-	uint32_t chunk = 0;
-	if ( lane_id() == 0u )
-		chunk = atomicAdd( head, 1u );
-	chunk = wave_bcast( chunk );
-	first = chunk * 64u;
-	return (unsigned long long) chunk * 64ull < total;
+	const uint32_t chunks = (uint32_t) ( ( total + 63ull ) >> 6 );
+	if ( g.next == g.end )
+	{
+		// g.end is the head position seen by the previous grab
+		const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
+		const uint32_t left = chunks > g.end ? chunks - g.end : 0u;
+		uint32_t n = left / ( 2u * waves );
+		n = n < 1u ? 1u : ( n > maxGrab ? maxGrab : n );
+		uint32_t start = 0;
+		if ( lane_id() == 0u )
+			start = atomicAdd( head, n );
+		start = wave_bcast( start );
+		g.next = start;
+		g.end = start + n;
+	}
+	if ( g.next >= chunks )
+		return false;
+	first = g.next * 64u;
+	++g.next;
+	return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -632,9 +685,10 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
-	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
+	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	uint32_t first;
-	while ( next_chunk( &W.ctr->headClosest[slot], count, first ) )
+	Grab grab = { 0u, 0u };
+	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_GRAB ) )
 	{
 		const uint32_t e = first + lane_id();
 		RayHead rh;
@@ -676,11 +730,12 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 		const bool sphHit = valid && ( h.nearestB || prB ) && !( h.minT < prMinT ) && prB;
 		const bool hit = triHit || sphHit;
 
-		const uint32_t hidx = wave_append( &W.ctr->hitCount[slot], hit );
+		const uint32_t hidx = wave_append( &W.ctr->hitCount[slot].v, hit );
 		if ( hit )
 		{
-			W.hitA[hidx] = make_float4( __uint_as_float( e ), triHit ? h.minT : prMinT, h.minU, h.minV );
-			W.hitB[hidx] = make_uint2( triHit ? h.prN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? h.nearestB : prB ) );
+			const size_t ho = (size_t) slot * W.npix + hidx;
+			W.hitA[ho] = make_float4( __uint_as_float( e ), triHit ? h.minT : prMinT, h.minU, h.minV );
+			W.hitB[ho] = make_uint2( triHit ? h.prN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? h.nearestB : prB ) );
 		}
 		else if ( valid )
 		{
@@ -724,17 +779,18 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
-	const uint32_t hits = W.ctr->hitCount[slot];
-	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
+	const uint32_t hits = W.ctr->hitCount[slot].v;
+	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	const uint32_t total = hits * (uint32_t) S.nLights;      // < 2^31, checked by the host
 	uint32_t first;
-	while ( next_chunk( &W.ctr->headShadow[slot], total, first ) )
+	Grab grab = { 0u, 0u };
+	while ( next_chunk( &W.ctr->headShadow[slot].v, total, grab, first, RT_TRAV_GRAB ) )
 	{
 		const uint32_t i = first + lane_id();
 		if ( i >= total )
 			continue;
 		const uint32_t o = i / hits, hh = i - o * hits;
-		const float4 ha = W.hitA[hh];
+		const float4 ha = W.hitA[(size_t) slot * W.npix + hh];
 		RayHead rh;
 		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
 			continue;
@@ -773,18 +829,18 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 				while ( !alpha_round<STATS>( S, sh, R, st, t, d, a, tl ) ) {}
 			}
 		}
-		W.shadow[(size_t) o * W.npix + hh] = shadowed + clampf( a, 0.0f, 1.0f );
+		W.shadow[( (size_t) slot * S.nLights + o ) * W.npix + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
 	if ( STATS )
 		flush_tally( W, tl, true );
 }
 
 // ---------------------------------------------------------------------------
-// k_shade: lighting of the compacted hits of one slot + child ray generation
+// shading of the compacted hits of one slot: child rays (k_spawn), lighting (k_light)
 // ---------------------------------------------------------------------------
 
 // CL/rt_funcs_primitives.cl:450-564 with the shadow term taken from k_shadow
-DEVI f3 light_point( const DevScene &S, const Work &W, uint32_t h, f3 P, f3 N, const rt_material &mat, f3 viewer )
+DEVI f3 light_point( const DevScene &S, const Work &W, int slot, uint32_t h, f3 P, f3 N, const rt_material &mat, f3 viewer )
 {
 	f3 col = F3( 0.0f, 0.0f, 0.0f );
 	for ( int o = 0; o < S.nLights; ++o )
@@ -797,7 +853,7 @@ DEVI f3 light_point( const DevScene &S, const Work &W, uint32_t h, f3 P, f3 N, c
 		float d;
 		to_light( S, o, P, toLight, d );
 
-		float shadowed = W.shadow[(size_t) o * W.npix + h];
+		float shadowed = W.shadow[( (size_t) slot * S.nLights + o ) * W.npix + h];
 		shadowed *= mat.color.a;
 
 		f3 ambient = col_mult( lcol, rgb_of( mat.ambient ) );
@@ -831,7 +887,7 @@ DEVI void push_ray( const Work &W, int target, bool want, const Ray &r, uint32_t
 		bool mine = want && target == s;
 		if ( __ballot( mine ) == 0ull )
 			continue;
-		uint32_t idx = wave_append( &W.ctr->rayCount[s], mine );
+		uint32_t idx = wave_append( &W.ctr->rayCount[s].v, mine );
 		if ( mine )
 		{
 			size_t o = (size_t) ( s - 1 ) * W.npix + idx;
@@ -844,12 +900,17 @@ DEVI void push_ray( const Work &W, int target, bool want, const Ray &r, uint32_t
 	}
 }
 
-__global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int slot )
+// k_spawn: for every hit of one slot the shading normal and the child rays.
+// This is the part of the shading the next slot's traversal waits for; the
+// lighting (k_light) needs the shadow sums and runs beside later traversals.
+__global__ __launch_bounds__( RT_BLOCK ) void k_spawn( DevScene S, Work W, int slot )
 {
-	const uint32_t count = W.ctr->hitCount[slot];
-	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot];
+	const uint32_t count = W.ctr->hitCount[slot].v;
+	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
+	const size_t base = (size_t) slot * W.npix;
 	uint32_t first;
-	while ( next_chunk( &W.ctr->headShade[slot], count, first ) )
+	Grab grab = { 0u, 0u };
+	while ( next_chunk( &W.ctr->headSpawn[slot].v, count, grab, first, RT_STREAM_GRAB ) )
 	{
 		const uint32_t h = first + lane_id();
 		bool valid = h < count;
@@ -860,8 +921,8 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 		uint2 hb = make_uint2( 0u, 0u );
 		if ( valid )
 		{
-			ha = W.hitA[h];
-			hb = W.hitB[h];
+			ha = W.hitA[base + h];
+			hb = W.hitB[base + h];
 			valid = load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh );
 		}
 
@@ -898,24 +959,25 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 				matIdx = __float_as_uint( c.y );
 				N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
 			}
+			W.hitN[base + h] = make_float4( N.x, N.y, N.z, __uint_as_float( matIdx ) );
 
-			const rt_material mat = S.mats[matIdx];
-			const f3 col = light_point( S, W, h, P, N, mat, rh.ray.src );
+			const rt_material &mat = S.mats[matIdx];
+			const f3 refl = rgb_of( mat.reflect );
+			const float alpha = mat.color.a;
 
 			sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
 
 			// reflection ray :643-655
-			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 )
-				&& ( ( mat.reflect.r + mat.reflect.g + mat.reflect.b ) > 0.0f ) )
+			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 ) && ( ( refl.x + refl.y + refl.z ) > 0.0f ) )
 			{
 				++sp;
 				pushRefl = true;
 				rRefl.dest = reflect3( rh.ray.dest, N );
 				rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
-				cRefl = rgb_of( mat.reflect );
+				cRefl = refl;
 			}
 			// refraction ray :657-677
-			if ( ( ( sp + 1 ) < S.stackSize ) && ( mat.color.a < 0.99f ) )
+			if ( ( ( sp + 1 ) < S.stackSize ) && ( alpha < 0.99f ) )
 			{
 				const float nRel = ENV_OPT_DENSITY / mat.optDens;
 				const float cosI = dot3( N, rh.ray.dest );
@@ -927,17 +989,9 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 					rRefr.dest = norm3( sub3( mul3( rh.ray.dest, nRel ),
 						mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
 					rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
-					cRefr = F3( mat.color.r * mat.lightFalloff, mat.color.g * mat.lightFalloff,
-						mat.color.b * mat.lightFalloff );
+					const float lf = mat.lightFalloff;
+					cRefr = F3( mat.color.r * lf, mat.color.g * lf, mat.color.b * lf );
 				}
-			}
-
-			const size_t o = (size_t) slot * W.npix + rh.pix;
-			W.res[o] = make_float4( col.x, col.y, col.z, __int_as_float( parent_of( rh.pk ) ) );
-			if ( slot > 0 )
-			{
-				const f3 fw = fold_weight( W, slot, __float_as_uint( ha.x ), rh.pk, P );
-				W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
 			}
 			if ( slot == 0 || pushRefl || pushRefr )
 				W.stackPos[rh.pix] = (uint32_t) sp;
@@ -947,6 +1001,39 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_shade( DevScene S, Work W, int s
 		const int reflSlot = sp - ( pushRefr ? 1 : 0 );
 		push_ray( W, reflSlot, pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
 		push_ray( W, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
+	}
+}
+
+// k_light: colour of every hit of one slot (needs k_shadow's sums and
+// k_spawn's normals) and the weight of the slot in its parent
+__global__ __launch_bounds__( RT_BLOCK ) void k_light( DevScene S, Work W, int slot )
+{
+	const uint32_t count = W.ctr->hitCount[slot].v;
+	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
+	const size_t base = (size_t) slot * W.npix;
+	uint32_t first;
+	Grab grab = { 0u, 0u };
+	while ( next_chunk( &W.ctr->headShade[slot].v, count, grab, first, RT_STREAM_GRAB ) )
+	{
+		const uint32_t h = first + lane_id();
+		if ( h >= count )
+			continue;
+		const float4 ha = W.hitA[base + h];
+		RayHead rh;
+		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
+			continue;
+		const f3 P = add3( mul3( rh.ray.dest, ha.y ), rh.ray.src );
+		const float4 hn = W.hitN[base + h];
+		const rt_material mat = S.mats[__float_as_uint( hn.w )];
+		const f3 col = light_point( S, W, slot, h, P, F3( hn.x, hn.y, hn.z ), mat, rh.ray.src );
+
+		const size_t o = base + rh.pix;
+		W.res[o] = make_float4( col.x, col.y, col.z, __int_as_float( parent_of( rh.pk ) ) );
+		if ( slot > 0 )
+		{
+			const f3 fw = fold_weight( W, slot, __float_as_uint( ha.x ), rh.pk, P );
+			W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
+		}
 	}
 }
 
@@ -1032,17 +1119,22 @@ struct rt_hip_ctx
 	DevScene S;
 	Work W;
 	DevBuf nodes, recs, shade, mats, spheres, sphereMat, lights;
-	DevBuf ctr, rays, hitA, hitB, res, fac, shadow, stackPos, hitId, spill, frame;
+	DevBuf ctr, rays, hitA, hitB, hitN, res, fac, shadow, stackPos, hitId, spill, frame;
 	uint64_t nNodes = 0, nRecs = 0, nTris = 0, nMats = 0;
 	uint64_t maxMatTree = 0, maxMatSphere = 0;   // highest material slot referenced
 	int treeDepth = 0;
 	int allocStack = 0;           // stack size the work buffers were sized for
 	bool workDirty = true;
-	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridShade = 0;
+	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridSpawn = 0, gridLight = 0;
+	int occShadow[2] = { 1, 1 };
+	hipStream_t aux[2] = { nullptr, nullptr };   // shadow + lighting passes (even / odd slots)
+	hipEvent_t evHit[RT_MAX_SLOTS] = {}, evSpawn[RT_MAX_SLOTS] = {}, evLit[RT_MAX_SLOTS] = {};
+	int overlap = 1;
 	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
 	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
-	hipEvent_t ev[RT_TIMED_FRAMES][3 * RT_MAX_SLOTS + 3] = {};
+	// [frame][(slot * 4 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop
+	hipEvent_t ev[RT_TIMED_FRAMES][8 * RT_MAX_SLOTS + 4] = {};
 	bool haveEvents = false;
 	int timedSlots = 0, timedFrames = 0;
 	uint32_t validPixels = 0;
@@ -1088,6 +1180,8 @@ static int upload( rt_hip_ctx *c, DevBuf &b, const void *src, size_t bytes )
 	return 0;
 }
 
+void rt_hip_destroy( rt_hip_ctx *c );
+
 rt_hip_ctx *rt_hip_create( int device )
 {
 	int n = rt_hip_device_count();
@@ -1123,10 +1217,10 @@ rt_hip_ctx *rt_hip_create( int device )
 
 	// persistent grids: one resident wave set per CU, as many blocks as fit
 	int occ = 0;
-	struct { const void *f; int *dst; } ks[5] = {
-		{ (const void *) k_closest<false>, &c->gridClosest[0] }, { (const void *) k_closest<true>, &c->gridClosest[1] },
-		{ (const void *) k_shadow<false>, &c->gridShadow[0] }, { (const void *) k_shadow<true>, &c->gridShadow[1] },
-		{ (const void *) k_shade, &c->gridShade } };
+	struct { const void *f; int *dst; int *occ; } ks[6] = {
+		{ (const void *) k_closest<false>, &c->gridClosest[0], nullptr }, { (const void *) k_closest<true>, &c->gridClosest[1], nullptr },
+		{ (const void *) k_shadow<false>, &c->gridShadow[0], &c->occShadow[0] }, { (const void *) k_shadow<true>, &c->gridShadow[1], &c->occShadow[1] },
+		{ (const void *) k_spawn, &c->gridSpawn, nullptr }, { (const void *) k_light, &c->gridLight, nullptr } };
 	for ( auto &k : ks )
 	{
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
@@ -1136,7 +1230,26 @@ rt_hip_ctx *rt_hip_create( int device )
 		if ( occ > RT_OCC_CAP ) occ = RT_OCC_CAP;
 #endif
 		*k.dst = occ * c->numCU;
+		if ( k.occ ) *k.occ = occ;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
+	}
+	// the streaming passes gain nothing from more than a few waves per SIMD
+	if ( c->gridSpawn > RT_STREAM_OCC * c->numCU ) c->gridSpawn = RT_STREAM_OCC * c->numCU;
+	if ( c->gridLight > RT_STREAM_OCC * c->numCU ) c->gridLight = RT_STREAM_OCC * c->numCU;
+
+	int prLow = 0, prHigh = 0;
+	bool ok = hipDeviceGetStreamPriorityRange( &prLow, &prHigh ) == hipSuccess;
+	for ( auto &a : c->aux )
+		ok = ok && hipStreamCreateWithPriority( &a, hipStreamNonBlocking, prLow ) == hipSuccess;
+	for ( int k = 0; k < RT_MAX_SLOTS && ok; ++k )
+		ok = hipEventCreateWithFlags( &c->evHit[k], hipEventDisableTiming ) == hipSuccess
+			&& hipEventCreateWithFlags( &c->evSpawn[k], hipEventDisableTiming ) == hipSuccess
+			&& hipEventCreateWithFlags( &c->evLit[k], hipEventDisableTiming ) == hipSuccess;
+	if ( !ok )
+	{
+		fail( "rt_hip_create: auxiliary stream / event creation failed" );
+		rt_hip_destroy( c );
+		return nullptr;
 	}
 	return c;
 }
@@ -1147,8 +1260,15 @@ void rt_hip_destroy( rt_hip_ctx *c )
 		return;
 	(void) hipSetDevice( c->device );
 	(void) hipStreamSynchronize( c->stream );
+	for ( auto &a : c->aux ) if ( a ) { (void) hipStreamSynchronize( a ); (void) hipStreamDestroy( a ); }
+	for ( int k = 0; k < RT_MAX_SLOTS; ++k )
+	{
+		if ( c->evHit[k] ) (void) hipEventDestroy( c->evHit[k] );
+		if ( c->evSpawn[k] ) (void) hipEventDestroy( c->evSpawn[k] );
+		if ( c->evLit[k] ) (void) hipEventDestroy( c->evLit[k] );
+	}
 	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights,
-		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->res, &c->fac, &c->shadow, &c->stackPos, &c->hitId, &c->spill, &c->frame };
+		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->hitN, &c->res, &c->fac, &c->shadow, &c->stackPos, &c->hitId, &c->spill, &c->frame };
 	for ( DevBuf *b : all )
 		if ( b->p ) (void) hipFree( b->p );
 	if ( c->haveEvents )
@@ -1326,6 +1446,11 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 		c->workDirty = true;
 		return 0;
 	}
+	if ( key == RT_PARAM_OVERLAP )
+	{
+		c->overlap = value ? 1 : 0;
+		return 0;
+	}
 	return fail( "rt_hip_set_param: unknown key %d", key );
 }
 
@@ -1339,15 +1464,17 @@ static int prepare_work( rt_hip_ctx *c )
 	int slots = S.stackSize;
 	if ( ensure( c, c->ctr, sizeof( Counters ) ) ) return 1;
 	if ( ensure( c, c->rays, 4 * sizeof( float4 ) * npix * (size_t) ( slots > 1 ? slots - 1 : 1 ) ) ) return 1;
-	if ( ensure( c, c->hitA, sizeof( float4 ) * npix ) ) return 1;
-	if ( ensure( c, c->hitB, sizeof( uint2 ) * npix ) ) return 1;
+	if ( ensure( c, c->hitA, sizeof( float4 ) * npix * slots ) ) return 1;
+	if ( ensure( c, c->hitB, sizeof( uint2 ) * npix * slots ) ) return 1;
+	if ( ensure( c, c->hitN, sizeof( float4 ) * npix * slots ) ) return 1;
 	if ( ensure( c, c->res, sizeof( float4 ) * npix * slots ) ) return 1;
 	if ( ensure( c, c->fac, sizeof( float4 ) * npix * slots ) ) return 1;
-	if ( ensure( c, c->shadow, sizeof( float ) * npix * (size_t) ( S.nLights > 0 ? S.nLights : 1 ) ) ) return 1;
+	if ( ensure( c, c->shadow, sizeof( float ) * npix * slots * (size_t) ( S.nLights > 0 ? S.nLights : 1 ) ) ) return 1;
 	if ( ensure( c, c->stackPos, sizeof( uint32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->hitId, sizeof( int32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->frame, sizeof( rt_argb ) * npix ) ) return 1;
-	if ( ensure( c, c->spill, sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
+	// three strips: the closest-hit chain and one per auxiliary stream
+	if ( ensure( c, c->spill, 3 * sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
 	size_t per = npix * (size_t) ( slots > 1 ? slots - 1 : 1 );
 	W.ctr = (Counters *) c->ctr.p;
 	W.rayA = (float4 *) c->rays.p;
@@ -1356,6 +1483,7 @@ static int prepare_work( rt_hip_ctx *c )
 	W.rayD = W.rayC + per;
 	W.hitA = (float4 *) c->hitA.p;
 	W.hitB = (uint2 *) c->hitB.p;
+	W.hitN = (float4 *) c->hitN.p;
 	W.res = (float4 *) c->res.p;
 	W.fac = (float4 *) c->fac.p;
 	W.shadow = (float *) c->shadow.p;
@@ -1404,31 +1532,68 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		c->timedFrames = 0;
 	}
 	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
-	int evi = 0;
+	hipEvent_t *evFold = ev + 8 * RT_MAX_SLOTS, *evFrame = evFold + 2;
+	const bool overlap = c->overlap && S.stackSize > 1;
+	const int lights = S.nLights > 0 ? S.nLights : 1;
 
+	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
 	HIPCHK( hipMemsetAsync( c->ctr.p, 0, sizeof( Counters ), s ) );
 	if ( W.npix == 0 )
 		return 0;
 	for ( int k = 0; k < S.stackSize; ++k )
 	{
+		hipEvent_t *e = ev + 8 * k;
+		hipStream_t x = overlap ? c->aux[k & 1] : s;
+		// every traversal running at the same time needs its own stack-overflow strip
+		Work Wx = W;
+		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + ( k & 1 ) ) * W.spillStride * RT_SPILL_CAP;
+
 		// a persistent grid never needs more waves than there are chunks
-		uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
-		int gc = c->gridClosest[stats], gw = c->gridShadow[stats], gs = c->gridShade;
+		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
+		int gc = c->gridClosest[stats], gp = c->gridSpawn, gl = c->gridLight;
+		// beside the chain a shadow pass leaves part of every CU to it
+		int gw = overlap && c->occShadow[stats] > RT_AUX_OCC ? RT_AUX_OCC * c->numCU : c->gridShadow[stats];
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
-		if ( k == 0 && want * (uint32_t) ( S.nLights > 0 ? S.nLights : 1 ) < (uint32_t) gw ) gw = (int) ( want ? want * ( S.nLights > 0 ? S.nLights : 1 ) : 1u );
-		if ( k == 0 && want < (uint32_t) gs ) gs = (int) ( want ? want : 1u );
-		if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
+		if ( k == 0 && want * (uint32_t) lights < (uint32_t) gw ) gw = (int) ( want ? want * lights : 1u );
+		if ( k == 0 && want < (uint32_t) gp ) gp = (int) ( want ? want : 1u );
+		if ( k == 0 && want < (uint32_t) gl ) gl = (int) ( want ? want : 1u );
+
+		if ( timing ) HIPCHK( hipEventRecord( e[0], s ) );
 		if ( stats ) hipLaunchKernelGGL( k_closest<true>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
 		else hipLaunchKernelGGL( k_closest<false>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
-		if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
-		if ( stats ) hipLaunchKernelGGL( k_shadow<true>, dim3( gw ), dim3( RT_BLOCK ), 0, s, S, W, k );
-		else hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, s, S, W, k );
-		if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
-		hipLaunchKernelGGL( k_shade, dim3( gs ), dim3( RT_BLOCK ), 0, s, S, W, k );
+		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
+		if ( overlap )
+		{
+			HIPCHK( hipEventRecord( c->evHit[k], s ) );
+			HIPCHK( hipStreamWaitEvent( x, c->evHit[k], 0 ) );
+		}
+
+		if ( timing ) HIPCHK( hipEventRecord( e[4], x ) );
+		if ( stats ) hipLaunchKernelGGL( k_shadow<true>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wx, k );
+		else hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wx, k );
+		if ( timing ) HIPCHK( hipEventRecord( e[5], x ) );
+
+		if ( timing ) HIPCHK( hipEventRecord( e[2], s ) );
+		hipLaunchKernelGGL( k_spawn, dim3( gp ), dim3( RT_BLOCK ), 0, s, S, W, k );
+		if ( timing ) HIPCHK( hipEventRecord( e[3], s ) );
+		if ( overlap )
+		{
+			HIPCHK( hipEventRecord( c->evSpawn[k], s ) );
+			HIPCHK( hipStreamWaitEvent( x, c->evSpawn[k], 0 ) );
+		}
+
+		if ( timing ) HIPCHK( hipEventRecord( e[6], x ) );
+		hipLaunchKernelGGL( k_light, dim3( gl ), dim3( RT_BLOCK ), 0, x, S, W, k );
+		if ( timing ) HIPCHK( hipEventRecord( e[7], x ) );
+		if ( overlap ) HIPCHK( hipEventRecord( c->evLit[k], x ) );
 	}
-	if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
+	if ( overlap )
+		for ( int k = 0; k < S.stackSize; ++k )
+			HIPCHK( hipStreamWaitEvent( s, c->evLit[k], 0 ) );
+	if ( timing ) HIPCHK( hipEventRecord( evFold[0], s ) );
 	hipLaunchKernelGGL( k_fold, dim3( ( W.npix + RT_BLOCK - 1 ) / RT_BLOCK ), dim3( RT_BLOCK ), 0, s, W, out, S.stackSize );
-	if ( timing ) HIPCHK( hipEventRecord( ev[evi++], s ) );
+	if ( timing ) HIPCHK( hipEventRecord( evFold[1], s ) );
+	if ( timing ) HIPCHK( hipEventRecord( evFrame[1], s ) );
 	if ( timing ) ++c->timedFrames;
 	HIPCHK( hipGetLastError() );
 	return 0;
@@ -1472,8 +1637,8 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	memset( out, 0, sizeof( *out ) );
 	out->raysClosest = c->validPixels;
-	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.rayCount[k];
-	for ( int k = 0; k < RT_MAX_SLOTS; ++k ) out->hits += h.hitCount[k];
+	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.rayCount[k].v;
+	for ( int k = 0; k < RT_MAX_SLOTS; ++k ) out->hits += h.hitCount[k].v;
 	out->raysShadow = out->hits * (uint64_t) c->S.nLights;
 	out->nodeVisits = h.nodeVisits;
 	out->triTests = h.triTests;
@@ -1487,8 +1652,8 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	out->triSlotsShadow = h.triSlotsShadow;
 	for ( int k = 0; k < RT_MAX_SLOTS; ++k )
 	{
-		out->slotRays[k] = k ? h.rayCount[k] : c->validPixels;
-		out->slotHits[k] = h.hitCount[k];
+		out->slotRays[k] = k ? h.rayCount[k].v : c->validPixels;
+		out->slotHits[k] = h.hitCount[k].v;
 	}
 	return 0;
 }
@@ -1505,23 +1670,24 @@ int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 	for ( int f = 0; f < frames; ++f )
 	{
 		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
-		int e = 0;
+		static const int dst[4] = { 0, 2, 1, 2 };     // closest, spawn, shadow, light
 		float t = 0.0f;
 		for ( int k = 0; k < n; ++k )
-			for ( int j = 0; j < 3; ++j, ++e )
+			for ( int j = 0; j < 4; ++j )
 			{
-				HIPCHK( hipEventElapsedTime( &t, ev[e], ev[e + 1] ) );
-				ms[j] += t;
+				HIPCHK( hipEventElapsedTime( &t, ev[8 * k + 2 * j], ev[8 * k + 2 * j + 1] ) );
+				ms[dst[j]] += t;
 			}
-		HIPCHK( hipEventElapsedTime( &t, ev[e], ev[e + 1] ) );
+		HIPCHK( hipEventElapsedTime( &t, ev[8 * RT_MAX_SLOTS], ev[8 * RT_MAX_SLOTS + 1] ) );
 		ms[3] += t;
-		HIPCHK( hipEventElapsedTime( &t, ev[0], ev[e + 1] ) );
+		HIPCHK( hipEventElapsedTime( &t, ev[8 * RT_MAX_SLOTS + 2], ev[8 * RT_MAX_SLOTS + 3] ) );
 		ms[4] += t;
 	}
 	for ( int i = 0; i < 5; ++i ) ms[i] /= (float) frames;
-	launches[0] = launches[1] = launches[2] = n;
+	launches[0] = launches[1] = n;
+	launches[2] = 2 * n;
 	launches[3] = 1;
-	launches[4] = 3 * n + 1;
+	launches[4] = 4 * n + 1;
 	c->timedFrames = 0;
 	return 0;
 }
