@@ -65,6 +65,9 @@
 #ifndef RT_STREAM_GRAB
 #define RT_STREAM_GRAB 16u   // chunks a streaming wave takes per atomic (at most)
 #endif
+#ifndef RT_RESV_BLOCK
+#define RT_RESV_BLOCK 256u   // list entries a wave reserves per atomic when the list is long
+#endif
 #ifndef RT_STREAM_OCC
 #define RT_STREAM_OCC 4      // blocks per CU of the streaming (non-traversal) passes
 #endif
@@ -108,6 +111,7 @@ struct Counters
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
 	unsigned long long nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;   // lane-slots spent (STATS)
+	unsigned long long validRays[RT_MAX_SLOTS], validHits[RT_MAX_SLOTS];      // filled by k_count_valid on request
 };
 
 struct Work
@@ -126,6 +130,7 @@ struct Work
 	int32_t *hitId;                       // optional primary hit ids
 	uint2  *spill;                        // traversal stack overflow
 	uint32_t npix, tilesX, nChunks0, spillStride;
+	uint32_t cap;                         // entries per ray list / hit list (npix + room for reservation holes)
 };
 
 struct Ray { f3 src, dest, inv; };
@@ -174,6 +179,52 @@ DEVI uint32_t wave_append( uint32_t *counter, bool want )
 		base = atomicAdd( counter, (uint32_t) __popcll( m ) );
 	base = __shfl( base, __ffsll( (long long) m ) - 1 );
 	return base + lanes_below( m );
+}
+
+// Append through a wave-private reservation.  One atomic per 64-entry chunk
+// on a list's end position is one atomic per chunk on ONE address, and the L2
+// executes those one after the other (about 12 ns each): a pass over 130 000
+// chunks cannot finish in under 1.5 ms whatever else it does.  A wave
+// therefore reserves `block` entries at a time and hands them out locally.
+// What is left of a reservation when the next batch does not fit, or when
+// the wave exits, is filled with invalid entries (`mark`), which every
+// consumer of the list skips; block = 0 reserves exactly what is needed (no
+// holes, one atomic per batch), which is what short lists use.
+#define RT_INVALID 0xffffffffu
+struct Resv { uint32_t pos, end; };
+template <class Mark>
+DEVI void list_close( Resv &r, Mark mark )
+{
+	for ( uint32_t i = r.pos + lane_id(); i < r.end; i += 64u )
+		mark( i );
+	r.pos = r.end;
+}
+template <class Mark>
+DEVI uint32_t list_append( uint32_t *counter, Resv &r, bool want, uint32_t block, Mark mark )
+{
+	const unsigned long long m = __ballot( want );
+	const uint32_t n = (uint32_t) __popcll( m );
+	if ( n == 0u )
+		return 0u;
+	if ( r.pos + n > r.end )
+	{
+		list_close( r, mark );
+		const uint32_t take = block > n ? block : n;
+		uint32_t base = 0;
+		if ( lane_id() == 0u )
+			base = atomicAdd( counter, take );
+		base = wave_bcast( base );
+		r.pos = base;
+		r.end = base + take;
+	}
+	const uint32_t idx = r.pos + lanes_below( m );
+	r.pos += n;
+	return idx;
+}
+// reservation size for the output of a pass over `count` input entries
+DEVI uint32_t resv_block( uint32_t count )
+{
+	return count >= gridDim.x * ( RT_BLOCK / 64u ) * 64u * 4u ? RT_RESV_BLOCK : 0u;
 }
 
 // LDS part of the traversal stacks of one workgroup: entry k of thread t sits
@@ -591,8 +642,11 @@ DEVI bool load_ray( const DevScene &S, const Work &W, int slot, uint32_t e, uint
 	}
 	if ( e >= count )
 		return false;
-	size_t o = (size_t) ( slot - 1 ) * W.npix + e;
-	float4 a = W.rayA[o], b = W.rayB[o];
+	size_t o = (size_t) ( slot - 1 ) * W.cap + e;
+	float4 a = W.rayA[o];
+	if ( __float_as_uint( a.w ) == RT_INVALID )       // hole left by a reservation
+		return false;
+	float4 b = W.rayB[o];
 	rh.ray.src = F3( a.x, a.y, a.z );
 	rh.ray.dest = F3( b.x, b.y, b.z );
 	rh.ray.inv = rcp3( rh.ray.dest );
@@ -607,7 +661,7 @@ DEVI bool load_ray( const DevScene &S, const Work &W, int slot, uint32_t e, uint
 // rayD = parent hit point (the refraction weight needs the distance).
 DEVI f3 fold_weight( const Work &W, int slot, uint32_t e, uint32_t pk, f3 P )
 {
-	size_t o = (size_t) ( slot - 1 ) * W.npix + e;
+	size_t o = (size_t) ( slot - 1 ) * W.cap + e;
 	float4 c = W.rayC[o];
 	if ( ( pk >> 8 ) & 1u )
 		return F3( c.x, c.y, c.z );
@@ -688,6 +742,10 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	uint32_t first;
 	Grab grab = { 0u, 0u };
+	Resv resv = { 0u, 0u };
+	const uint32_t block = resv_block( count );
+	const size_t hbase = (size_t) slot * W.cap;
+	auto holeHit = [&]( uint32_t i ) { W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); };
 	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_GRAB ) )
 	{
 		const uint32_t e = first + lane_id();
@@ -730,10 +788,10 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 		const bool sphHit = valid && ( h.nearestB || prB ) && !( h.minT < prMinT ) && prB;
 		const bool hit = triHit || sphHit;
 
-		const uint32_t hidx = wave_append( &W.ctr->hitCount[slot].v, hit );
+		const uint32_t hidx = list_append( &W.ctr->hitCount[slot].v, resv, hit, block, holeHit );
 		if ( hit )
 		{
-			const size_t ho = (size_t) slot * W.npix + hidx;
+			const size_t ho = hbase + hidx;
 			W.hitA[ho] = make_float4( __uint_as_float( e ), triHit ? h.minT : prMinT, h.minU, h.minV );
 			W.hitB[ho] = make_uint2( triHit ? h.prN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? h.nearestB : prB ) );
 		}
@@ -752,6 +810,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 		if ( slot == 0 && wantIds && valid )
 			W.hitId[rh.pix] = triHit ? (int32_t) h.prN : ( sphHit ? -2 - (int32_t) prN : -1 );
 	}
+	list_close( resv, holeHit );
 	if ( STATS )
 		flush_tally( W, tl, false );
 }
@@ -790,7 +849,9 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 		if ( i >= total )
 			continue;
 		const uint32_t o = i / hits, hh = i - o * hits;
-		const float4 ha = W.hitA[(size_t) slot * W.npix + hh];
+		const float4 ha = W.hitA[(size_t) slot * W.cap + hh];
+		if ( __float_as_uint( ha.x ) == RT_INVALID )
+			continue;
 		RayHead rh;
 		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
 			continue;
@@ -829,7 +890,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 				while ( !alpha_round<STATS>( S, sh, R, st, t, d, a, tl ) ) {}
 			}
 		}
-		W.shadow[( (size_t) slot * S.nLights + o ) * W.npix + hh] = shadowed + clampf( a, 0.0f, 1.0f );
+		W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
 	if ( STATS )
 		flush_tally( W, tl, true );
@@ -853,7 +914,7 @@ DEVI f3 light_point( const DevScene &S, const Work &W, int slot, uint32_t h, f3 
 		float d;
 		to_light( S, o, P, toLight, d );
 
-		float shadowed = W.shadow[( (size_t) slot * S.nLights + o ) * W.npix + h];
+		float shadowed = W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + h];
 		shadowed *= mat.color.a;
 
 		f3 ambient = col_mult( lcol, rgb_of( mat.ambient ) );
@@ -879,18 +940,21 @@ DEVI f3 light_point( const DevScene &S, const Work &W, int slot, uint32_t h, f3 
 	return col;
 }
 
-DEVI void push_ray( const Work &W, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
+DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
 {
 	// lanes of one wave may target different slots: aggregate per slot
+#pragma unroll
 	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
 	{
 		bool mine = want && target == s;
 		if ( __ballot( mine ) == 0ull )
 			continue;
-		uint32_t idx = wave_append( &W.ctr->rayCount[s].v, mine );
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
+		uint32_t idx = list_append( &W.ctr->rayCount[s].v, rv[s], mine, block,
+			[&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
 		if ( mine )
 		{
-			size_t o = (size_t) ( s - 1 ) * W.npix + idx;
+			size_t o = lbase + idx;
 			W.rayA[o] = make_float4( r.src.x, r.src.y, r.src.z, __uint_as_float( pix ) );
 			W.rayB[o] = make_float4( r.dest.x, r.dest.y, r.dest.z,
 				__uint_as_float( (uint32_t) parent | ( (uint32_t) type << 8 ) ) );
@@ -907,9 +971,11 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_spawn( DevScene S, Work W, int s
 {
 	const uint32_t count = W.ctr->hitCount[slot].v;
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
-	const size_t base = (size_t) slot * W.npix;
+	const size_t base = (size_t) slot * W.cap;
 	uint32_t first;
 	Grab grab = { 0u, 0u };
+	Resv rv[RT_MAX_SLOTS] = {};
+	const uint32_t block = resv_block( count );
 	while ( next_chunk( &W.ctr->headSpawn[slot].v, count, grab, first, RT_STREAM_GRAB ) )
 	{
 		const uint32_t h = first + lane_id();
@@ -923,7 +989,7 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_spawn( DevScene S, Work W, int s
 		{
 			ha = W.hitA[base + h];
 			hb = W.hitB[base + h];
-			valid = load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh );
+			valid = __float_as_uint( ha.x ) != RT_INVALID && load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh );
 		}
 
 		bool pushRefl = false, pushRefr = false;
@@ -999,8 +1065,14 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_spawn( DevScene S, Work W, int s
 
 		// slot numbers: reflection takes the first new slot, refraction the next
 		const int reflSlot = sp - ( pushRefr ? 1 : 0 );
-		push_ray( W, reflSlot, pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
-		push_ray( W, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
+		push_ray( W, rv, block, reflSlot, pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
+		push_ray( W, rv, block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
+	}
+#pragma unroll
+	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
+	{
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
+		list_close( rv[s], [&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
 	}
 }
 
@@ -1010,7 +1082,7 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_light( DevScene S, Work W, int s
 {
 	const uint32_t count = W.ctr->hitCount[slot].v;
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
-	const size_t base = (size_t) slot * W.npix;
+	const size_t base = (size_t) slot * W.cap;
 	uint32_t first;
 	Grab grab = { 0u, 0u };
 	while ( next_chunk( &W.ctr->headShade[slot].v, count, grab, first, RT_STREAM_GRAB ) )
@@ -1020,14 +1092,14 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_light( DevScene S, Work W, int s
 			continue;
 		const float4 ha = W.hitA[base + h];
 		RayHead rh;
-		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
+		if ( __float_as_uint( ha.x ) == RT_INVALID || !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
 			continue;
 		const f3 P = add3( mul3( rh.ray.dest, ha.y ), rh.ray.src );
 		const float4 hn = W.hitN[base + h];
 		const rt_material mat = S.mats[__float_as_uint( hn.w )];
 		const f3 col = light_point( S, W, slot, h, P, F3( hn.x, hn.y, hn.z ), mat, rh.ray.src );
 
-		const size_t o = base + rh.pix;
+		const size_t o = (size_t) slot * W.npix + rh.pix;
 		W.res[o] = make_float4( col.x, col.y, col.z, __int_as_float( parent_of( rh.pk ) ) );
 		if ( slot > 0 )
 		{
@@ -1085,6 +1157,20 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_fold( Work W, rt_argb *out, int 
 	px.g = (unsigned char) ( 255.0f * col[0].y );
 	px.b = (unsigned char) ( 255.0f * col[0].z );
 	out[p] = px;
+}
+
+// number of entries of a list that are not reservation holes (statistics only);
+// word = index of the 32-bit word of the float4 that carries the marker
+__global__ __launch_bounds__( RT_BLOCK ) void k_count_valid( const float4 *list, const uint32_t *n, int word, unsigned long long *out )
+{
+	uint32_t cnt = 0;
+	for ( uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < *n; i += gridDim.x * RT_BLOCK )
+		cnt += ( (const uint32_t *) ( list + i ) )[word] != RT_INVALID;
+	const unsigned long long m = __ballot( cnt != 0u );
+	for ( int o = 32; o > 0; o >>= 1 )
+		cnt += __shfl_down( cnt, o );
+	if ( lane_id() == 0u && m )
+		atomicAdd( out, (unsigned long long) cnt );
 }
 
 // ---------------------------------------------------------------------------
@@ -1454,6 +1540,12 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 	return fail( "rt_hip_set_param: unknown key %d", key );
 }
 
+static size_t list_capacity( const rt_hip_ctx *c, size_t npix )
+{
+	static_assert( RT_RESV_BLOCK >= 256u || RT_RESV_BLOCK == 0u, "the 4/3 bound below assumes blocks of at least 256 entries" );
+	return npix + npix / 3 + 64 + (size_t) c->maxGrid * ( RT_BLOCK / 64 ) * RT_RESV_BLOCK;
+}
+
 static int prepare_work( rt_hip_ctx *c )
 {
 	DevScene &S = c->S;
@@ -1463,19 +1555,23 @@ static int prepare_work( rt_hip_ctx *c )
 	if ( npix == 0 ) npix = 1;
 	int slots = S.stackSize;
 	if ( ensure( c, c->ctr, sizeof( Counters ) ) ) return 1;
-	if ( ensure( c, c->rays, 4 * sizeof( float4 ) * npix * (size_t) ( slots > 1 ? slots - 1 : 1 ) ) ) return 1;
-	if ( ensure( c, c->hitA, sizeof( float4 ) * npix * slots ) ) return 1;
-	if ( ensure( c, c->hitB, sizeof( uint2 ) * npix * slots ) ) return 1;
-	if ( ensure( c, c->hitN, sizeof( float4 ) * npix * slots ) ) return 1;
+	// A list holds at most npix valid entries.  A reservation is given up with
+	// fewer than 64 of its RT_RESV_BLOCK entries unused, and every wave leaves at
+	// most one unfinished reservation behind: that bounds the holes.
+	const size_t cap = list_capacity( c, npix );
+	if ( ensure( c, c->rays, 4 * sizeof( float4 ) * cap * (size_t) ( slots > 1 ? slots - 1 : 1 ) ) ) return 1;
+	if ( ensure( c, c->hitA, sizeof( float4 ) * cap * slots ) ) return 1;
+	if ( ensure( c, c->hitB, sizeof( uint2 ) * cap * slots ) ) return 1;
+	if ( ensure( c, c->hitN, sizeof( float4 ) * cap * slots ) ) return 1;
 	if ( ensure( c, c->res, sizeof( float4 ) * npix * slots ) ) return 1;
 	if ( ensure( c, c->fac, sizeof( float4 ) * npix * slots ) ) return 1;
-	if ( ensure( c, c->shadow, sizeof( float ) * npix * slots * (size_t) ( S.nLights > 0 ? S.nLights : 1 ) ) ) return 1;
+	if ( ensure( c, c->shadow, sizeof( float ) * cap * slots * (size_t) ( S.nLights > 0 ? S.nLights : 1 ) ) ) return 1;
 	if ( ensure( c, c->stackPos, sizeof( uint32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->hitId, sizeof( int32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->frame, sizeof( rt_argb ) * npix ) ) return 1;
 	// three strips: the closest-hit chain and one per auxiliary stream
 	if ( ensure( c, c->spill, 3 * sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
-	size_t per = npix * (size_t) ( slots > 1 ? slots - 1 : 1 );
+	size_t per = cap * (size_t) ( slots > 1 ? slots - 1 : 1 );
 	W.ctr = (Counters *) c->ctr.p;
 	W.rayA = (float4 *) c->rays.p;
 	W.rayB = W.rayA + per;
@@ -1492,6 +1588,7 @@ static int prepare_work( rt_hip_ctx *c )
 	W.hitId = (int32_t *) c->hitId.p;
 	W.spill = (uint2 *) c->spill.p;
 	W.npix = (uint32_t) ( (size_t) S.w * (size_t) S.localH );
+	W.cap = (uint32_t) cap;
 	W.tilesX = (uint32_t) ( ( S.w + 7 ) / 8 );
 	W.nChunks0 = W.tilesX * (uint32_t) ( ( S.localH + 7 ) / 8 );
 	W.spillStride = (uint32_t) c->maxGrid * RT_BLOCK;
@@ -1512,7 +1609,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	HIPCHK( hipSetDevice( c->device ) );
 	if ( c->S.nSpheres == 0 && !c->S.spheres ) { rt_sphere z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_spheres( c, &z, 0 ) ) return 1; }
 	if ( c->S.nLights == 0 && !c->S.lights ) { rt_point_light z; memset( &z, 0, sizeof( z ) ); if ( rt_hip_upload_lights( c, &z, 0 ) ) return 1; }
-	if ( (unsigned long long) c->S.w * c->S.localH * (unsigned long long) ( c->S.nLights > 0 ? c->S.nLights : 1 ) >= ( 1ull << 31 ) )
+	if ( (unsigned long long) list_capacity( c, (size_t) c->S.w * c->S.localH ) * (unsigned long long) ( c->S.nLights > 0 ? c->S.nLights : 1 ) >= ( 1ull << 31 ) )
 		return fail( "rt_hip_render: pixels x lights exceeds the 31-bit work-item range" );
 	if ( ( c->workDirty || c->workLights != c->S.nLights ) && prepare_work( c ) ) return 1;
 	const bool stats = flags & RT_HIP_STATS, ids = flags & RT_HIP_HITIDS, timing = flags & RT_HIP_TIMING;
@@ -1632,13 +1729,24 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	if ( !c || !out ) return fail( "rt_hip_get_stats: bad arguments" );
 	HIPCHK( hipSetDevice( c->device ) );
 	if ( !c->ctr.p ) return fail( "rt_hip_get_stats: nothing rendered" );
+	// list lengths include reservation holes: count the valid entries
+	Counters *d = (Counters *) c->ctr.p;
+	HIPCHK( hipMemsetAsync( d->validRays, 0, sizeof( d->validRays ) + sizeof( d->validHits ), c->stream ) );
+	for ( int k = 0; k < c->S.stackSize; ++k )
+	{
+		if ( k > 0 )
+			hipLaunchKernelGGL( k_count_valid, dim3( 1024 ), dim3( RT_BLOCK ), 0, c->stream,
+				(const float4 *) c->W.rayA + (size_t) ( k - 1 ) * c->W.cap, (const uint32_t *) &d->rayCount[k].v, 3, &d->validRays[k] );
+		hipLaunchKernelGGL( k_count_valid, dim3( 1024 ), dim3( RT_BLOCK ), 0, c->stream,
+			(const float4 *) c->W.hitA + (size_t) k * c->W.cap, (const uint32_t *) &d->hitCount[k].v, 0, &d->validHits[k] );
+	}
 	Counters h;
 	HIPCHK( hipMemcpyAsync( &h, c->ctr.p, sizeof( h ), hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	memset( out, 0, sizeof( *out ) );
 	out->raysClosest = c->validPixels;
-	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.rayCount[k].v;
-	for ( int k = 0; k < RT_MAX_SLOTS; ++k ) out->hits += h.hitCount[k].v;
+	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.validRays[k];
+	for ( int k = 0; k < RT_MAX_SLOTS; ++k ) out->hits += h.validHits[k];
 	out->raysShadow = out->hits * (uint64_t) c->S.nLights;
 	out->nodeVisits = h.nodeVisits;
 	out->triTests = h.triTests;
@@ -1652,8 +1760,8 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	out->triSlotsShadow = h.triSlotsShadow;
 	for ( int k = 0; k < RT_MAX_SLOTS; ++k )
 	{
-		out->slotRays[k] = k ? h.rayCount[k].v : c->validPixels;
-		out->slotHits[k] = h.hitCount[k].v;
+		out->slotRays[k] = k ? h.validRays[k] : c->validPixels;
+		out->slotHits[k] = h.validHits[k];
 	}
 	return 0;
 }
