@@ -59,11 +59,11 @@
 #ifndef RT_AUX_OCC
 #define RT_AUX_OCC    4      // blocks per CU of a shadow pass that runs beside the closest-hit chain
 #endif
-#ifndef RT_TRAV_GRAB
-#define RT_TRAV_GRAB   1u    // chunks a traversal wave takes per atomic
+#ifndef RT_TRAV_DYN
+#define RT_TRAV_DYN   8u     // eighths of a list the traversal passes hand out dynamically (8 = all but the first round)
 #endif
-#ifndef RT_STREAM_GRAB
-#define RT_STREAM_GRAB 16u   // chunks a streaming wave takes per atomic (at most)
+#ifndef RT_STREAM_DYN
+#define RT_STREAM_DYN 1u     // the same for the streaming passes
 #endif
 #ifndef RT_RESV_BLOCK
 #define RT_RESV_BLOCK 256u   // list entries a wave reserves per atomic when the list is long
@@ -693,41 +693,52 @@ DEVI StackRef make_stack( const Work &W )
 	return st;
 }
 
-// Work distribution: every wave pulls 64-entry chunks from a device counter
-// until the list is exhausted.  Atomics on ONE address are executed strictly
-// one after the other by the L2 (roughly 12 ns each on this chip), which at
-// one atomic per chunk bounds a launch from below by chunks x 12 ns: more
-// than the work itself for the streaming passes.  Those take several chunks
-// per atomic, many while the list is long and one at a time near its end
-// (guided self-scheduling).  The traversal passes take one chunk at a time:
-// their chunks are long enough, and measured, waves that walk through
-// consecutive chunks on their own are slower (2 chunks +3 %, 8 chunks +27 %).
-// (Narrower chunks for short lists were measured too: the long rays of the
-// deep slots are not shortened by them and the extra waves cost more than
-// they save.)
-struct Grab { uint32_t next, end; };
-DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_t &first, uint32_t maxGrab )
+// Work distribution over the resident waves of a launch, in 64-entry chunks.
+// Atomics on ONE address are executed strictly one after the other by the L2
+// (about 12 ns each on this chip): one atomic per chunk bounds a pass from
+// below by chunks x 12 ns, and a launch in which every wave first has to ask
+// for work starts with waves x 12 ns (75 us) of queueing.  So:
+//   - a first share of the list is dealt out without atomics, round by round:
+//     chunk = round * waves + wave (neighbouring waves, neighbouring chunks);
+//   - the rest (`dynShare` eighths) goes through the counter and evens out
+//     the waves.  The streaming passes, whose chunks all cost the same, keep
+//     that rest small.  The traversal passes deal out only the first round
+//     statically: ray cost follows the image (background against silhouette)
+//     and a fixed wave -> chunk pattern follows it too (measured: 6/8 static
+//     makes the frame 40 % slower);
+//   - lists of at most two chunks per wave are dealt out entirely statically.
+// Measured alternatives that lost: looking at the counter with a plain load
+// before asking (loads of a line under atomic fire take far longer than the
+// atomic: frame 2.6x slower); several consecutive chunks per atomic in the
+// traversal passes (2 chunks +3 %, 8 chunks +27 %); narrower chunks for short
+// lists (the long rays of the deep slots are not shortened by them).
+struct Grab { uint32_t round; };
+DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_t &first, uint32_t dynShare )
 {
 	const uint32_t chunks = (uint32_t) ( ( total + 63ull ) >> 6 );
-	if ( g.next == g.end )
+	const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
+	const uint32_t wave = blockIdx.x * ( RT_BLOCK / 64u ) + ( threadIdx.x >> 6 );
+	// dynShare = 8: one static round, the rest through the counter
+	const uint32_t rounds = chunks <= 2u * waves ? ( chunks + waves - 1u ) / waves
+		: ( dynShare >= 8u ? 1u : (uint32_t) ( (unsigned long long) chunks * ( 8u - dynShare ) / ( 8ull * waves ) ) );
+	uint32_t c;
+	if ( g.round < rounds )
 	{
-		// g.end is the head position seen by the previous grab
-		const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
-		const uint32_t left = chunks > g.end ? chunks - g.end : 0u;
-		uint32_t n = left / ( 2u * waves );
-		n = n < 1u ? 1u : ( n > maxGrab ? maxGrab : n );
-		uint32_t start = 0;
-		if ( lane_id() == 0u )
-			start = atomicAdd( head, n );
-		start = wave_bcast( start );
-		g.next = start;
-		g.end = start + n;
+		c = g.round * waves + wave;
+		++g.round;
 	}
-	if ( g.next >= chunks )
-		return false;
-	first = g.next * 64u;
-	++g.next;
-	return true;
+	else
+	{
+		const uint32_t base = rounds * waves;
+		if ( base >= chunks )
+			return false;
+		uint32_t k = 0;
+		if ( lane_id() == 0u )
+			k = atomicAdd( head, 1u );
+		c = base + wave_bcast( k );
+	}
+	first = c * 64u;
+	return c < chunks;
 }
 
 // ---------------------------------------------------------------------------
@@ -741,12 +752,12 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 
 	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	uint32_t first;
-	Grab grab = { 0u, 0u };
+	Grab grab = { 0u };
 	Resv resv = { 0u, 0u };
 	const uint32_t block = resv_block( count );
 	const size_t hbase = (size_t) slot * W.cap;
 	auto holeHit = [&]( uint32_t i ) { W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); };
-	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_GRAB ) )
+	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_DYN ) )
 	{
 		const uint32_t e = first + lane_id();
 		RayHead rh;
@@ -842,8 +853,8 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	const uint32_t total = hits * (uint32_t) S.nLights;      // < 2^31, checked by the host
 	uint32_t first;
-	Grab grab = { 0u, 0u };
-	while ( next_chunk( &W.ctr->headShadow[slot].v, total, grab, first, RT_TRAV_GRAB ) )
+	Grab grab = { 0u };
+	while ( next_chunk( &W.ctr->headShadow[slot].v, total, grab, first, RT_TRAV_DYN ) )
 	{
 		const uint32_t i = first + lane_id();
 		if ( i >= total )
@@ -973,10 +984,10 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_spawn( DevScene S, Work W, int s
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	const size_t base = (size_t) slot * W.cap;
 	uint32_t first;
-	Grab grab = { 0u, 0u };
+	Grab grab = { 0u };
 	Resv rv[RT_MAX_SLOTS] = {};
 	const uint32_t block = resv_block( count );
-	while ( next_chunk( &W.ctr->headSpawn[slot].v, count, grab, first, RT_STREAM_GRAB ) )
+	while ( next_chunk( &W.ctr->headSpawn[slot].v, count, grab, first, RT_STREAM_DYN ) )
 	{
 		const uint32_t h = first + lane_id();
 		bool valid = h < count;
@@ -1084,8 +1095,8 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_light( DevScene S, Work W, int s
 	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
 	const size_t base = (size_t) slot * W.cap;
 	uint32_t first;
-	Grab grab = { 0u, 0u };
-	while ( next_chunk( &W.ctr->headShade[slot].v, count, grab, first, RT_STREAM_GRAB ) )
+	Grab grab = { 0u };
+	while ( next_chunk( &W.ctr->headShade[slot].v, count, grab, first, RT_STREAM_DYN ) )
 	{
 		const uint32_t h = first + lane_id();
 		if ( h >= count )
