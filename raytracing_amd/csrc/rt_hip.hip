@@ -57,7 +57,7 @@
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
 #define RT_TIMED_FRAMES 32
 #ifndef RT_AUX_OCC
-#define RT_AUX_OCC    4      // blocks per CU of a shadow pass that runs beside the closest-hit chain
+#define RT_AUX_OCC    2      // blocks per CU of a shadow pass that runs beside the closest-hit chain
 #endif
 #ifndef RT_TRAV_DYN
 #define RT_TRAV_DYN   8u     // eighths of a list the traversal passes hand out dynamically (8 = all but the first round)
