@@ -146,6 +146,12 @@ int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
  * With RT_PARAM_OVERLAP = 1 passes share the chip, so ms[0..3] add up to more
  * than ms[4]; set it to 0 to time every pass running alone. */
 int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );
+/* Device self-test (no reference counterpart): the triangle test replaces the
+ * IEEE division 1 / det by a hardware reciprocal plus one Newton step where
+ * that is exact.  Evaluates both for all 2^32 float bit patterns; *mismatches
+ * = inputs for which the value the kernels would use differs from the
+ * division (must be 0), *fastPath = inputs that take the short path. */
+int  rt_hip_selftest_rcp( rt_hip_ctx *c, uint64_t *mismatches, uint64_t *fastPath );
 
 #ifdef __cplusplus
 }

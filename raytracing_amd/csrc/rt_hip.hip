@@ -324,6 +324,35 @@ DEVI TriRay tri_ray( f3 src, f3 dest )
 // re-vectorising scalar results through extra moves)
 DEVI float own_reg( float x ) { asm( "" : "+v"( x ) ); return x; }
 
+// Correctly rounded 1 / x.  The hardware reciprocal is good to one unit in the
+// last place; one Newton step carried out with two fused multiply-adds then
+// lands on the correctly rounded quotient (Markstein) as long as neither x
+// nor 1 / x leaves the normal range.  `exact` tells whether that held: the
+// estimate is then a normal number.  Where it is false for any lane the
+// caller takes the full IEEE division for the whole wave instead (zero
+// determinants: degenerate or edge-on triangles).  rt_hip_selftest_rcp checks
+// the claim for every one of the 2^32 float bit patterns on the device.
+DEVI float rcp_newton( float x, bool &exact )
+{
+	const float r = __builtin_amdgcn_rcpf( x );
+	exact = __builtin_amdgcn_classf( r, 0x108 );      // +/- normal
+	const float e = __builtin_fmaf( -x, r, 1.0f );
+	return __builtin_fmaf( r, e, r );
+}
+DEVI float rcp_exact( float x )
+{
+	bool ok;
+	float r = rcp_newton( x, ok );
+	if ( __ballot( !ok ) != 0ull )
+	{
+		// an empty volatile statement: without it the compiler evaluates the
+		// division unconditionally and merely selects the result
+		asm volatile( "" );
+		r = 1.0f / x;
+	}
+	return r;
+}
+
 // one 48-byte leaf record as three 16-byte loads
 struct Rec { float4 a, b, c; };
 DEVI Rec load_rec( const float4 *recs, uint32_t i )
@@ -364,7 +393,7 @@ DEVI bool ray_tri( const TriRay &R, const Rec &rc, float &t, float &u, float &v 
 	// (p.dist, p.e1) = ((px*X + py*Y) + pz*Z)
 	const v2f ud = ( splat( n.y ) * X + splat( n.x ) * Y ) + splat( pz ) * Z;
 	const float det = ud.y;
-	const float inv = 1.0f / det;
+	const float inv = rcp_exact( det );
 	// dist x e1
 	const v2f c1 = Y * swap2( Z );                       // (ty*e1z, e1y*tz)
 	const v2f c2 = Z * swap2( X );                       // (tz*e1x, e1z*tx)
@@ -1184,6 +1213,25 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_count_valid( const float4 *list,
 		atomicAdd( out, (unsigned long long) cnt );
 }
 
+// every float bit pattern: rcp_exact against the IEEE division
+__global__ __launch_bounds__( RT_BLOCK ) void k_selftest_rcp( unsigned long long *mismatches, unsigned long long *fastLanes )
+{
+	unsigned long long bad = 0, fast = 0;
+	for ( unsigned long long i = (unsigned long long) blockIdx.x * RT_BLOCK + threadIdx.x; i < ( 1ull << 32 ); i += (unsigned long long) gridDim.x * RT_BLOCK )
+	{
+		const float x = __uint_as_float( (uint32_t) i );
+		bool ok;
+		const float n = rcp_newton( x, ok );
+		const float q = 1.0f / x;
+		fast += ok;
+		// the value the kernels use: Newton where the estimate is a normal number, the division elsewhere
+		const float used = ok ? n : q;
+		bad += __float_as_uint( used ) != __float_as_uint( q ) && !( q != q && used != used );
+	}
+	atomicAdd( mismatches, bad );
+	atomicAdd( fastLanes, fast );
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1774,6 +1822,23 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 		out->slotRays[k] = k ? h.validRays[k] : c->validPixels;
 		out->slotHits[k] = h.validHits[k];
 	}
+	return 0;
+}
+
+int rt_hip_selftest_rcp( rt_hip_ctx *c, uint64_t *mismatches, uint64_t *fastPath )
+{
+	if ( !c || !mismatches || !fastPath ) return fail( "rt_hip_selftest_rcp: bad arguments" );
+	HIPCHK( hipSetDevice( c->device ) );
+	unsigned long long *d = nullptr, h[2] = { 0, 0 };
+	HIPCHK( hipMalloc( &d, sizeof( h ) ) );
+	HIPCHK( hipMemsetAsync( d, 0, sizeof( h ), c->stream ) );
+	hipLaunchKernelGGL( k_selftest_rcp, dim3( 4096 ), dim3( RT_BLOCK ), 0, c->stream, d, d + 1 );
+	hipError_t e = hipMemcpyAsync( h, d, sizeof( h ), hipMemcpyDeviceToHost, c->stream );
+	if ( e == hipSuccess ) e = hipStreamSynchronize( c->stream );
+	(void) hipFree( d );
+	HIPCHK( e );
+	*mismatches = h[0];
+	*fastPath = h[1];
 	return 0;
 }
 

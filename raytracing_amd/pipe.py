@@ -226,6 +226,12 @@ class HipRenderer:
         names = ("closest", "shadow", "shade", "fold", "frame")
         return dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n]))
 
+    def selftest_rcp(self):
+        """(mismatches, fast-path inputs) of the exact-reciprocal shortcut over all 2^32 floats."""
+        bad, fast = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.rt_hip_selftest_rcp(self._c, C.byref(bad), C.byref(fast)), "rt_hip_selftest_rcp")
+        return int(bad.value), int(fast.value)
+
 
 class RenderPipe:
     """The reference's render-pipe call sequence (rt_funcs_render_pipe.h)."""

@@ -249,3 +249,33 @@ def test_config3_4k_sampled_against_oracle():
     assert same == 1.0
     assert sc.w * sc.h <= st["raysClosest"] <= 5 * sc.w * sc.h
     assert st["raysShadow"] == st["hits"] <= st["raysClosest"]
+
+
+def test_exact_reciprocal_shortcut_equals_ieee_division_for_every_float():
+    """The triangle test computes 1/det as hardware reciprocal + one Newton
+    step where the estimate is a normal number and as the IEEE division
+    elsewhere (the oracle and the reference's host code divide).  All 2^32 bit
+    patterns are evaluated on the device: the two must never differ."""
+    r = HipRenderer(0)
+    bad, fast = r.selftest_rcp()
+    r.close()
+    assert bad == 0, f"{bad} inputs round differently"
+    assert fast > 0.95 * 2 ** 32 * (252 / 256), "the short path should cover nearly all normal inputs"
+
+
+def test_overlapped_and_in_order_schedules_give_the_same_frame():
+    """RT_PARAM_OVERLAP only changes on which stream the shadow / lighting passes run."""
+    from raytracing_amd.pipe import RT_PARAM_OVERLAP
+    sc = scenes.wavy_grid_scene(48, 160, 96)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 14, 7)
+    r = HipRenderer(0)
+    r.load_scene(sc, tree)
+    out = []
+    for ov in (1, 0, 1):
+        r.set_param(RT_PARAM_OVERLAP, ov)
+        r.render(RT_HIP_HITIDS)
+        out.append((r.read_frame().copy(), r.read_hit_ids().copy(), r.stats()["raysClosest"]))
+    r.close()
+    for img, ids, n in out[1:]:
+        assert np.array_equal(img, out[0][0]) and np.array_equal(ids, out[0][1]) and n == out[0][2]
