@@ -28,14 +28,14 @@ import torch.distributed as dist
 
 from raytracing_amd import dist as rdist
 from raytracing_amd import scenes
-from raytracing_amd.pipe import RT_HIP_STATS, RT_HIP_TIMING, FlatTree, HipRenderer
+from raytracing_amd.pipe import RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_OVERLAP, FlatTree, HipRenderer
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 
 # kd-tree of the benchmark: the reference's split rule with its two limits made
 # run-time parameters (the reference's fixed depth 10 leaves ~2000 triangles
 # per leaf on this scene)
-TREE_DEPTH, TREE_LEAF = 28, 7
+TREE_DEPTH, TREE_LEAF = 26, 12
 
 WORKLOADS = {
     "config3": dict(make=scenes.config3, text="1M-triangle displaced sphere + floor, 3840x2160, "
@@ -49,6 +49,19 @@ def algorithmic_bytes(nodes, tris, primary, hits):
     """8 B per kd node visited + 48 B per triangle tested + 4 B frame-buffer
     write per primary ray + 128 B of shading data per shaded hit."""
     return 8 * nodes + 48 * tris + 4 * primary + 128 * hits
+
+
+def measured_traffic(args, kernel, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter
+    passes of this same command (profiles/r01_traffic.json: FETCH_SIZE doubled
+    as the gfx950 correction prescribes, plus WRITE_SIZE), or None when that
+    file does not cover this configuration.  Counters cannot be read live."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    key = f"{args.workload}/depth{args.depth}/leaf{args.leaf}/gpus{world}/{'serial' if args.no_overlap else 'overlap'}"
+    return t.get(key, {}).get("k_" + kernel)
 
 
 def cpu_baseline(sc, tree, seconds=15.0):
@@ -81,6 +94,8 @@ def main():
     ap.add_argument("--depth", type=int, default=TREE_DEPTH)
     ap.add_argument("--leaf", type=int, default=TREE_LEAF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -108,6 +123,7 @@ def main():
     stream = torch.cuda.current_stream()
     r = HipRenderer(local_rank, stream=stream.cuda_stream)
     r.load_scene(sc, tree)
+    r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
     r.set_tile(rdist.BAND_H, world, rank)
     rows = r.local_rows
     pad = rdist.max_local_rows(sc.h, rdist.BAND_H, world)
@@ -147,6 +163,16 @@ def main():
     elapsed = float(el.item())
     rays_frame = float(cnt[0] + cnt[1])
 
+    # ---- outside the timed region: the same frame with every pass alone on the
+    # chip (what a kernel takes when it does not share the GPU with the passes
+    # that the normal schedule runs beside it)
+    r.set_param(RT_PARAM_OVERLAP, 0)
+    for _ in range(3):
+        r.render(RT_HIP_TIMING, d_out=frame_local.data_ptr())
+    r.sync()
+    kms_iso, _ = r.kernel_times()
+    r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
+
     # ---- roofline of the dominant kernel (counting pass, outside the timed region)
     r.render(RT_HIP_STATS, d_out=frame_local.data_ptr())
     r.sync()
@@ -183,14 +209,18 @@ def main():
                        "kd_tree": {"max_depth": args.depth, "max_prims_in_leaf": args.leaf, "depth": int(tree.depth),
                                    "nodes": int(len(tree.nodes)), "triangle_refs": int(len(tree.recs)),
                                    "host_build_s": round(build_s, 3)},
+                       "schedule": "passes in order on one stream" if args.no_overlap else
+                                   "closest-hit/spawn chain on the main stream, shadow + lighting passes on two auxiliary "
+                                   "streams (they overlap the chain; per-kernel times include the time a pass shares the chip)",
                        "rays_per_frame": int(rays_frame), "closest_rays": int(cnt[0]), "shadow_rays": int(cnt[1]),
                        "parallelism": "single GPU" if world == 1 else
                                       f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "
                                       "rows gathered on rank 0 (RCCL)"},
             "kernel_ms_per_frame_rank0": {k: round(x, 4) for k, x in kms.items()},
+            "kernel_ms_per_frame_isolated_rank0": {k: round(x, 4) for k, x in kms_iso.items()},
             "roofline": {"bound": "hbm", "kernel": "k_" + dominant,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args, dominant, world),
                          "launches_per_frame": n_launch,
                          "algorithmic_bytes_per_launch": int(dom_bytes / n_launch),
                          "avg_launch_ms": round(dom_ms / n_launch, 4),

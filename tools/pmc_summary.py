@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
 names = sorted({c for k in tot for c in tot[k]})
 rows = [["kernel", "dispatches"] + names]
 for k in sorted(tot):
-    if not any(x in k for x in ("k_closest", "k_shadow", "k_shade", "k_fold")):
+    if not any(x in k for x in ("k_closest", "k_shadow", "k_spawn", "k_light", "k_fold")):
         continue
     rows.append([k, max(calls[k].values())] + [("%.6g" % tot[k][c]) if c in tot[k] else "" for c in names])
 out = "\n".join(",".join(str(x) for x in r) for r in rows)

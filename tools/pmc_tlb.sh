@@ -4,7 +4,7 @@
 set -u
 OUT=${1:-gpurun_out/pmc_tlb}
 shift || true
-ARGS=${*:-config3 28 7 2}
+ARGS=${*:-config3 26 12 2}
 export PYTHONPATH=.
 export TMPDIR=/tmp
 mkdir -p "$OUT"

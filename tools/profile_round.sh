@@ -1,0 +1,18 @@
+#!/bin/bash
+# Profiles of one round, written under gpurun_out/<tag>/ on the GPU box:
+#   bench.json / bench.err     the default bench.py line
+#   stats/                     rocprofv3 --kernel-trace --stats of the same command
+#   pmc/                       counter passes (one rocprofv3 run each) over a short run of the same frame
+# Usage: tools/profile_round.sh <tag>
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+export PYTHONPATH=. TMPDIR=/tmp
+mkdir -p $OUT
+timeout -k 10 400 python3 -u bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+echo bench done
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+echo stats done
+tools/pmc_passes.sh $OUT/pmc || exit 1
+RT_OVERLAP=0 tools/pmc_passes.sh $OUT/pmc_serial || exit 1
+echo profile_round done

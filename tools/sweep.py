@@ -18,6 +18,8 @@ def main():
         tree = FlatTree.build(v, t, depth, leaf, 0, stop, axes)
         tb = time.time() - t0
         r.load_scene(sc, tree)
+        if os.environ.get("RT_PARTS"):
+            r.set_tile(16, int(os.environ["RT_PARTS"]), 0)
         if os.environ.get("RT_OVERLAP") is not None:
             r.set_param(RT_PARAM_OVERLAP, int(os.environ["RT_OVERLAP"]))
         best = None
