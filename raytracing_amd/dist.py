@@ -63,3 +63,11 @@ def gather_frame(local, h, w, band_h=BAND_H, dst=0, group=None):
     if rank != dst:
         return None
     return assemble(bufs, h, w, band_h)
+
+
+def sequence_frames(n_frames, n_parts, part, start=0):
+    """Frames of a sequence rendered by `part`: frame f goes to rank f mod
+    n_parts.  Frames are independent given the scene (only the camera
+    changes), so a sequence needs no collective at all."""
+    first = start + ((part - start) % n_parts)
+    return list(range(first, n_frames, n_parts))

@@ -64,3 +64,10 @@ def test_gather_frame_two_ranks_gloo(h, w, band):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("n,parts", [(240, 8), (7, 3), (2, 4), (0, 2)])
+def test_sequence_frames_partition(n, parts):
+    got = [rdist.sequence_frames(n, parts, p) for p in range(parts)]
+    assert sorted(f for g in got for f in g) == list(range(n))
+    assert all(f % parts == p for p, g in enumerate(got) for f in g)

@@ -279,3 +279,29 @@ def test_overlapped_and_in_order_schedules_give_the_same_frame():
     r.close()
     for img, ids, n in out[1:]:
         assert np.array_equal(img, out[0][0]) and np.array_equal(ids, out[0][1]) and n == out[0][2]
+
+
+@pytest.mark.parametrize("frame", [0, 37, 121])
+def test_fly_through_frames_match_the_oracle(frame):
+    """Config-5 style: camera on the orbit, reflective + refractive sphere, six rays per pixel."""
+    sc = scenes.config5_frame(frame, 192, 108, lon=60, lat=30)
+    img, ids, st, tree = hip_render(sc, 16, 7)
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    same, exact = assert_parity(img, ids, oimg, oid)
+    assert same == 1.0 and exact == 1.0
+    assert st["raysClosest"] == ost["raysClosest"] and st["raysShadow"] == ost["raysShadow"]
+    tree.release()
+
+
+def test_fly_through_driver_single_rank(tmp_path):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "apps", "flythrough.py"), "--frames", "3", "--size", "160x96",
+                          "--lon", "40", "--lat", "20", "--depth", "14", "--leaf", "7", "--out", str(tmp_path / "pngs")],
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["frames"] == 3 and rec["rays_last_frame"] > 160 * 96
+    assert sorted(os.listdir(tmp_path / "pngs")) == ["10.png", "8.png", "9.png"]
