@@ -289,6 +289,10 @@ void rt_render_pipe_set_param( rt_render_pipe *pRp, int key, int value )
 		break;
 	case RT_PARAM_BUILD_THREADS: im->buildThreads = value; break;
 	case RT_PARAM_TREE_CACHE: im->treeCache = value; break;
+	case RT_PARAM_OVERLAP:
+		if ( rt_hip_set_param( im->hip, key, value ) )
+			die_hip( "rt_render_pipe_set_param" );
+		break;
 	default:
 		fprintf( stderr, "rt: unknown parameter %d\n", key );
 		exit( -3 );

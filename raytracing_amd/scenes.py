@@ -230,6 +230,11 @@ def config5_frame(frame, w=3840, h=2160, lon=1000, lat=500):
                         name=f"c5_frame{frame}", world=orbit_world(frame))
 
 
+def config5(w=3840, h=2160):
+    """One representative frame of the fly-through (camera a quarter of the way round)."""
+    return config5_frame(60, w, h)
+
+
 def wavy_grid_scene(n=32, w=96, h=64, with_sphere=True, reflect=0.3, alpha=0.5):
     """Small fixture scene: n x n wavy quad grid (2 n^2 triangles, reflective
     and refractive like the reference's water), a matte back wall, one
