@@ -524,10 +524,7 @@ DEVI bool trav_pop( const DevScene &S, const StackRef &st, Trav &t, Tally &tl )
 
 struct NearHit { float minT, minU, minV; uint32_t prN; int nearestB; };
 
-// One round of the closest-hit query, CL/rt_funcs_primitives.cl:165-252 with the
-// leaf loop :74-111 inlined; true = finished.  The per-leaf reset of the
-// running distance while the hit flag and the triangle id persist is the
-// reference's behaviour.
+// One triangle of the closest-hit leaf loop, CL/rt_funcs_primitives.cl:74-111.
 template <bool STATS>
 DEVI void nearest_tri( const TriRay &R, const Rec &rc, float &lt, NearHit &h, Tally &tl )
 {
@@ -543,38 +540,8 @@ DEVI void nearest_tri( const TriRay &R, const Rec &rc, float &lt, NearHit &h, Ta
 	}
 }
 
-template <bool STATS>
-DEVI bool nearest_round( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, Trav &t, NearHit &h, Tally &tl )
-{
-	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	trav_descend<STATS>( S, src, inv, dest, st, t, tl );
-	float lt = INFINITY;
-	// Two records are kept in flight and take turns (no register copies); the
-	// array ends with one spare record, so the look-ahead load of the last
-	// triangle stays inside the buffer.
-	uint32_t i = t.n.x;
-	const uint32_t end = i + ( t.n.y >> 2 );
-	if ( i != end )
-	{
-		Rec r0 = load_rec( S.recs, i );
-		for ( ;; )
-		{
-			Rec r1 = load_rec( S.recs, i + 1u );
-			nearest_tri<STATS>( R, r0, lt, h, tl );
-			if ( ++i == end ) break;
-			r0 = load_rec( S.recs, i + 1u );
-			nearest_tri<STATS>( R, r1, lt, h, tl );
-			if ( ++i == end ) break;
-		}
-	}
-	h.minT = lt;
-	if ( h.nearestB && ( h.minT < t.tFar ) )
-		return true;
-	return !trav_pop<STATS>( S, st, t, tl );
-}
-
-// One round of the shadow query: sum of the opacities of every triangle hit
-// before the light, CL/rt_funcs_primitives.cl:295-378 + :256-276; true = finished.
+// One triangle of the shadow query (sum of the opacities of every triangle hit
+// before the light), CL/rt_funcs_primitives.cl:256-276.
 template <bool STATS>
 DEVI void alpha_tri( const DevScene &S, const TriRay &R, const Rec &rc, const Trav &t, float d, float &alpha, Tally &tl )
 {
@@ -584,31 +551,204 @@ DEVI void alpha_tri( const DevScene &S, const TriRay &R, const Rec &rc, const Tr
 		alpha += S.mats[rec_mat( rc )].color.a;
 }
 
-template <bool STATS>
-DEVI bool alpha_round( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, Trav &t, float d, float &alpha, Tally &tl )
+// ---------------------------------------------------------------------------
+// Leaf scans of a sparse wave.  Towards the end of a chunk, and for whole
+// passes in the deep slots, a wave carries a handful of long rays: one lane
+// walks through its leaf triangle by triangle while sixty others idle.  When
+// at most RT_COOP_LANES lanes have a leaf to scan, the wave scans those leaves
+// one after the other with ALL lanes instead, lane i testing triangle i
+// against the owner's ray (broadcast through scalar registers).  The values
+// are the ones the owner would have computed; the owner's sequential rule
+// (strictly smaller distance wins, so the lowest index among equals) is the
+// minimum over the lanes with the lowest lane index among equals, and the
+// shadow sum is accumulated in ascending triangle order.
+// ---------------------------------------------------------------------------
+#ifndef RT_COOP_LANES
+#define RT_COOP_LANES 3
+#endif
+DEVI float lane_f( float x, uint32_t lane ) { return __uint_as_float( (uint32_t) __builtin_amdgcn_readlane( (int) __float_as_uint( x ), (int) lane ) ); }
+DEVI uint32_t lane_u( uint32_t x, uint32_t lane ) { return (uint32_t) __builtin_amdgcn_readlane( (int) x, (int) lane ); }
+DEVI float wave_min( float x )
 {
-	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	trav_descend<STATS>( S, src, inv, dest, st, t, tl );
-	uint32_t i = t.n.x;
-	const uint32_t end = i + ( t.n.y >> 2 );
-	if ( i != end )
+	for ( int o = 32; o > 0; o >>= 1 )
 	{
-		Rec r0 = load_rec( S.recs, i );
-		for ( ;; )
+		const float y = __shfl_xor( x, o );
+		x = y < x ? y : x;
+	}
+	return x;
+}
+DEVI TriRay lane_tri_ray( const Ray &r, uint32_t lane )
+{
+	return tri_ray( F3( lane_f( r.src.x, lane ), lane_f( r.src.y, lane ), lane_f( r.src.z, lane ) ),
+		F3( lane_f( r.dest.x, lane ), lane_f( r.dest.y, lane ), lane_f( r.dest.z, lane ) ) );
+}
+
+// closest-hit leaf scan of lane `owner` by the whole wave
+template <bool STATS>
+DEVI void nearest_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, uint32_t owner, float &lt, NearHit &h, Tally &tl )
+{
+	const uint32_t first = lane_u( t.n.x, owner ), cnt = lane_u( t.n.y, owner ) >> 2;
+	const TriRay R = lane_tri_ray( r, owner );
+	float best = INFINITY, bu = 0.0f, bv = 0.0f;
+	uint32_t bid = 0u;
+	bool found = false;
+	for ( uint32_t base = 0; base < cnt; base += 64u )
+	{
+		const uint32_t i = base + lane_id();
+		const bool ok = i < cnt;
+		const Rec rc = load_rec( S.recs, first + ( ok ? i : 0u ) );
+		float tt, u, v;
+		const bool hit = ray_tri( R, rc, tt, u, v ) && ok;
+		const float m = wave_min( hit ? tt : INFINITY );
+		if ( m < best )
 		{
-			Rec r1 = load_rec( S.recs, i + 1u );
-			alpha_tri<STATS>( S, R, r0, t, d, alpha, tl );
-			if ( ++i == end ) break;
-			r0 = load_rec( S.recs, i + 1u );
-			alpha_tri<STATS>( S, R, r1, t, d, alpha, tl );
-			if ( ++i == end ) break;
+			const uint32_t win = (uint32_t) __ffsll( (long long) __ballot( hit && tt == m ) ) - 1u;
+			best = m;
+			bu = lane_f( u, win );
+			bv = lane_f( v, win );
+			bid = lane_u( rec_tri( rc ), win );
+			found = true;
 		}
 	}
-	// the caller clamps the sum to [0,1]: with non-negative opacities it
-	// cannot drop below 1 again, the rest of the ray is irrelevant
-	if ( S.alphaMonotone && alpha >= 1.0f )
-		return true;
-	return !trav_pop<STATS>( S, st, t, tl );
+	if ( lane_id() == owner )
+	{
+		lt = best;
+		if ( found )
+		{
+			h.minU = bu;
+			h.minV = bv;
+			h.prN = bid;
+			h.nearestB = 1;
+		}
+		if ( STATS ) { tl.tris += cnt; tl.triSlots += 64.0f * (float) ( ( cnt + 63u ) / 64u ); }
+	}
+}
+
+// shadow leaf scan of lane `owner` by the whole wave
+template <bool STATS>
+DEVI void alpha_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, float d, uint32_t owner, float &alpha, Tally &tl )
+{
+	const uint32_t first = lane_u( t.n.x, owner ), cnt = lane_u( t.n.y, owner ) >> 2;
+	const TriRay R = lane_tri_ray( r, owner );
+	const float dO = lane_f( d, owner ), tN = lane_f( t.tNear, owner ), tF = lane_f( t.tFar, owner );
+	float sum = lane_f( alpha, owner );
+	for ( uint32_t base = 0; base < cnt; base += 64u )
+	{
+		const uint32_t i = base + lane_id();
+		const bool ok = i < cnt;
+		const Rec rc = load_rec( S.recs, first + ( ok ? i : 0u ) );
+		float tt, u, v;
+		const bool hit = ray_tri( R, rc, tt, u, v ) && ok && ( tt < dO ) && ( tt < tF ) && ( tt > tN );
+		float a = 0.0f;
+		if ( hit )
+			a = S.mats[rec_mat( rc )].color.a;
+		for ( unsigned long long w = __ballot( hit ); w; w &= w - 1ull )
+			sum += lane_f( a, (uint32_t) __ffsll( (long long) w ) - 1u );
+	}
+	if ( lane_id() == owner )
+	{
+		alpha = sum;
+		if ( STATS ) { tl.tris += cnt; tl.triSlots += 64.0f * (float) ( ( cnt + 63u ) / 64u ); }
+	}
+}
+
+// Closest-hit query of every lane with `live` set, CL/rt_funcs_primitives.cl:165-252:
+// rounds of descend / leaf scan / pop.  The per-leaf reset of the running
+// distance while the hit flag and the triangle id persist is the reference's
+// behaviour.  Control flow is wave-uniform, so that lanes whose ray is
+// finished stay available for the cooperative scans.
+template <bool STATS>
+DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl )
+{
+	const f3 src = r.src, inv = r.inv, dest = r.dest;
+	while ( __ballot( live ) != 0ull )
+	{
+		float lt = INFINITY;
+		uint32_t cnt = 0u;
+		if ( live )
+		{
+			trav_descend<STATS>( S, src, inv, dest, st, t, tl );
+			cnt = t.n.y >> 2;
+		}
+		unsigned long long m = __ballot( live && cnt != 0u );
+		if ( m != 0ull && (uint32_t) __popcll( m ) <= RT_COOP_LANES )
+		{
+			for ( ; m; m &= m - 1ull )
+				nearest_leaf_coop<STATS>( S, r, t, (uint32_t) __ffsll( (long long) m ) - 1u, lt, h, tl );
+		}
+		else if ( live && cnt != 0u )
+		{
+			// Two records are kept in flight and take turns (no register copies); the
+			// array ends with one spare record, so the look-ahead load of the last
+			// triangle stays inside the buffer.
+			uint32_t i = t.n.x;
+			const uint32_t end = i + cnt;
+			Rec r0 = load_rec( S.recs, i );
+			for ( ;; )
+			{
+				Rec r1 = load_rec( S.recs, i + 1u );
+				nearest_tri<STATS>( R, r0, lt, h, tl );
+				if ( ++i == end ) break;
+				r0 = load_rec( S.recs, i + 1u );
+				nearest_tri<STATS>( R, r1, lt, h, tl );
+				if ( ++i == end ) break;
+			}
+		}
+		if ( live )
+		{
+			h.minT = lt;
+			if ( h.nearestB && ( h.minT < t.tFar ) )
+				live = false;
+			else
+				live = trav_pop<STATS>( S, st, t, tl );
+		}
+	}
+}
+
+// shadow query of every lane with `live` set, CL/rt_funcs_primitives.cl:295-378
+template <bool STATS>
+DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, float d, float &alpha, Tally &tl )
+{
+	const f3 src = r.src, inv = r.inv, dest = r.dest;
+	while ( __ballot( live ) != 0ull )
+	{
+		uint32_t cnt = 0u;
+		if ( live )
+		{
+			trav_descend<STATS>( S, src, inv, dest, st, t, tl );
+			cnt = t.n.y >> 2;
+		}
+		unsigned long long m = __ballot( live && cnt != 0u );
+		if ( m != 0ull && (uint32_t) __popcll( m ) <= RT_COOP_LANES )
+		{
+			for ( ; m; m &= m - 1ull )
+				alpha_leaf_coop<STATS>( S, r, t, d, (uint32_t) __ffsll( (long long) m ) - 1u, alpha, tl );
+		}
+		else if ( live && cnt != 0u )
+		{
+			uint32_t i = t.n.x;
+			const uint32_t end = i + cnt;
+			Rec r0 = load_rec( S.recs, i );
+			for ( ;; )
+			{
+				Rec r1 = load_rec( S.recs, i + 1u );
+				alpha_tri<STATS>( S, R, r0, t, d, alpha, tl );
+				if ( ++i == end ) break;
+				r0 = load_rec( S.recs, i + 1u );
+				alpha_tri<STATS>( S, R, r1, t, d, alpha, tl );
+				if ( ++i == end ) break;
+			}
+		}
+		if ( live )
+		{
+			// the caller clamps the sum to [0,1]: with non-negative opacities it
+			// cannot drop below 1 again, the rest of the ray is irrelevant
+			if ( S.alphaMonotone && alpha >= 1.0f )
+				live = false;
+			else
+				live = trav_pop<STATS>( S, st, t, tl );
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -797,6 +937,8 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 		uint32_t prN = 0u;
 		int prB = 0;
 		NearHit h = { INFINITY, 0.0f, 0.0f, 0u, 0 };
+		Trav t;
+		bool live = false;
 
 		if ( valid )
 		{
@@ -816,11 +958,9 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 			// so their node and record loads fall into the same cache lines.
 			// (Refilling finished lanes with fresh rays mid-flight was measured and
 			// halves the speed on this workload: it destroys exactly that locality.)
-			Trav t;
-			const TriRay R = tri_ray( rh.ray.src, rh.ray.dest );
-			if ( trav_begin<STATS>( S, rh.ray, t, tl ) )
-				while ( !nearest_round<STATS>( S, rh.ray, R, st, t, h, tl ) ) {}
+			live = trav_begin<STATS>( S, rh.ray, t, tl );
 		}
+		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl );
 
 		// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
 		// "flag set, no valid distance, no sphere" is shaded as a miss
@@ -886,51 +1026,54 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 	while ( next_chunk( &W.ctr->headShadow[slot].v, total, grab, first, RT_TRAV_DYN ) )
 	{
 		const uint32_t i = first + lane_id();
-		if ( i >= total )
-			continue;
-		const uint32_t o = i / hits, hh = i - o * hits;
-		const float4 ha = W.hitA[(size_t) slot * W.cap + hh];
-		if ( __float_as_uint( ha.x ) == RT_INVALID )
-			continue;
+		bool item = i < total;
+		uint32_t o = 0u, hh = 0u;
+		float4 ha = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
 		RayHead rh;
-		if ( !load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh ) )
-			continue;
-		const f3 P = add3( mul3( rh.ray.dest, ha.y ), rh.ray.src );
-
-		f3 toLight;
-		float d;
-		to_light( S, (int) o, P, toLight, d );
-		Ray sh;
-		sh.dest = toLight;
-		sh.src = add3( P, mul3( toLight, EPSILON ) );
-		sh.inv = rcp3( toLight );
-		float a = 0.0f;
-		for ( int k = 0; k < S.nSpheres; ++k )           // :418-448
+		if ( item )
 		{
-			float ts;
-			int b = ray_sphere( sh, S.spheres[k], ts );
-			if ( b && ts < d )
-				a += S.mats[S.sphereMat[k]].color.a;
+			o = i / hits;
+			hh = i - o * hits;
+			ha = W.hitA[(size_t) slot * W.cap + hh];
+			item = __float_as_uint( ha.x ) != RT_INVALID && load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh );
 		}
-		const float shadowed = clampf( a, 0.0f, 1.0f );
-		// :289-293: the triangle sum starts at zero only once the scene box is hit
+
+		Ray sh;
 		Trav t;
-		if ( trav_begin<STATS>( S, sh, t, tl ) )
+		float d = 0.0f, a = 0.0f, shadowed = 0.0f;
+		bool live = false;
+		if ( item )
 		{
-			a = 0.0f;
-			// Only hits with tNear < t < tFar of their leaf AND t < d count, so the
-			// part of the ray beyond the light cannot contribute: walk
-			// [tNear, min(tFar, d)].  Leaves keep the same split distances, hence
-			// the same hits are counted.
-			if ( d < t.tFar )
-				t.tFar = d;
-			if ( t.tNear < t.tFar )
+			const f3 P = add3( mul3( rh.ray.dest, ha.y ), rh.ray.src );
+			f3 toLight;
+			to_light( S, (int) o, P, toLight, d );
+			sh.dest = toLight;
+			sh.src = add3( P, mul3( toLight, EPSILON ) );
+			sh.inv = rcp3( toLight );
+			for ( int k = 0; k < S.nSpheres; ++k )           // :418-448
 			{
-				const TriRay R = tri_ray( sh.src, sh.dest );
-				while ( !alpha_round<STATS>( S, sh, R, st, t, d, a, tl ) ) {}
+				float ts;
+				int b = ray_sphere( sh, S.spheres[k], ts );
+				if ( b && ts < d )
+					a += S.mats[S.sphereMat[k]].color.a;
+			}
+			shadowed = clampf( a, 0.0f, 1.0f );
+			// :289-293: the triangle sum starts at zero only once the scene box is hit
+			if ( trav_begin<STATS>( S, sh, t, tl ) )
+			{
+				a = 0.0f;
+				// Only hits with tNear < t < tFar of their leaf AND t < d count, so the
+				// part of the ray beyond the light cannot contribute: walk
+				// [tNear, min(tFar, d)].  Leaves keep the same split distances, hence
+				// the same hits are counted.
+				if ( d < t.tFar )
+					t.tFar = d;
+				live = t.tNear < t.tFar;
 			}
 		}
-		W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
+		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl );
+		if ( item )
+			W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
 	if ( STATS )
 		flush_tally( W, tl, true );
