@@ -168,19 +168,6 @@ DEVI uint32_t lanes_below( unsigned long long mask )
 	return __builtin_amdgcn_mbcnt_hi( (uint32_t) ( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t) mask, 0u ) );
 }
 
-// wave-aggregated append: lanes with `want` receive consecutive indices
-DEVI uint32_t wave_append( uint32_t *counter, bool want )
-{
-	unsigned long long m = __ballot( want );
-	uint32_t base = 0;
-	if ( m == 0ull )
-		return 0;
-	if ( lane_id() == (uint32_t) __ffsll( (long long) m ) - 1u )
-		base = atomicAdd( counter, (uint32_t) __popcll( m ) );
-	base = __shfl( base, __ffsll( (long long) m ) - 1 );
-	return base + lanes_below( m );
-}
-
 // Append through a wave-private reservation.  One atomic per 64-entry chunk
 // on a list's end position is one atomic per chunk on ONE address, and the L2
 // executes those one after the other (about 12 ns each): a pass over 130 000
@@ -461,10 +448,8 @@ DEVI uint32_t kd_inner( uint2 n, uint32_t cur, f3 src, f3 inv, f3 dest, float tN
 	return nearN;
 }
 
-// Per-lane traversal state.  A traversal is run in ROUNDS: descend to the next
-// leaf, scan it, then either finish or pop; between rounds the wave may hand
-// finished lanes a new ray (see the feeder below), which is what keeps lanes
-// busy when ray lengths differ.
+// Per-lane traversal state.  A traversal runs in rounds: descend to the next
+// leaf, scan it, then either finish or pop.
 struct Trav
 {
 	float tNear, tFar;
