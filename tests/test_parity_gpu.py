@@ -305,3 +305,42 @@ def test_fly_through_driver_single_rank(tmp_path):
     rec = json.loads(out.strip().splitlines()[-1])
     assert rec["frames"] == 3 and rec["rays_last_frame"] > 160 * 96
     assert sorted(os.listdir(tmp_path / "pngs")) == ["10.png", "8.png", "9.png"]
+
+
+def _soup_scene(seed, n_tris, alphas, w=128, h=96):
+    rng = np.random.RandomState(seed)
+    sc = scenes.Scene(f"soup{seed}", w, h, scenes.make_camera(w, h, hv=0.9))
+    v, t = random_soup(n_tris, seed)
+    sc.meshes.append(scenes.Mesh(v, t, 0))
+    sc.flatten = lambda: (v, t)                # keep per-triangle materials
+    for k, a in enumerate(alphas):
+        sc.materials[k] = T.make_material((a, *rng.uniform(0.2, 1, 3)), (0.0, 0.05, 0.05, 0.05),
+                                          (0.0, 0.6, 0.6, 0.6), (8.0, 0.4, 0.4, 0.4), (0.0, 0.3, 0.3, 0.3), 0.02, 1.2)
+    sc.lights.append(scenes.make_light((-20.0, -35.0, 0.0), 100.0))
+    return sc
+
+
+def test_negative_opacity_keeps_the_full_shadow_sum():
+    """With a negative material opacity the shadow sum can fall below 1 again,
+    so the early exit of the shadow query must be off; the result still has
+    to be the reference's sum over every triangle before the light."""
+    sc = _soup_scene(11, 3000, (1.0, -0.5, 0.7))
+    img, ids, st, tree = hip_render(sc, 14, 6)
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    same, exact = assert_parity(img, ids, oimg, oid)
+    assert same == 1.0 and exact >= 0.999
+    assert st["raysShadow"] == ost["raysShadow"]
+
+
+@pytest.mark.parametrize("depth,prims", [(0, 7), (3, 7), (8, 100)])
+def test_very_large_leaves(depth, prims):
+    """Leaves of hundreds of triangles (more than one wave's worth in the
+    cooperative scan, long per-lane scans otherwise)."""
+    sc = _soup_scene(12, 700, (1.0, 0.6, 1.0), w=96, h=64)
+    img, ids, st, tree = hip_render(sc, depth, prims)
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    same, exact = assert_parity(img, ids, oimg, oid)
+    assert same == 1.0 and exact >= 0.999
+    assert st["raysClosest"] == ost["raysClosest"] and st["raysShadow"] == ost["raysShadow"]
