@@ -93,6 +93,7 @@ typedef struct _rt_hip_stats
 #define RT_PARAM_MAX_PRIMS_IN_NODE 3   /* kd leaf size, default 7 (render pipe only)      */
 #define RT_PARAM_BUILD_THREADS     4   /* host builder threads, 0 = automatic             */
 #define RT_PARAM_TREE_CACHE        5   /* 1 = reuse the tree while geometry is unchanged  */
+#define RT_PARAM_GPU_BUILD         7   /* render pipe only: 1 = build the kd-tree on the GPU  */
 #define RT_PARAM_OVERLAP           6   /* 0 = run every pass on one stream, in order (default 1:
                                           shadow + lighting passes on auxiliary streams)  */
 
@@ -110,6 +111,14 @@ int  rt_hip_set_stream( rt_hip_ctx *c, void *hipStream );
 int  rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes,
 	const rt_hip_trirec *recs, uint64_t nRecs, const rt_hip_trishade *shade,
 	uint64_t nTris, const rt_box *bbox, int depth );
+/* Install a tree built on the device by rt_kdtree_build_device (rt_kdtree.h)
+ * without copying: the context takes ownership of the three buffers and
+ * clears *t.  Replaces rt_hip_upload_tree for geometry that changes every frame. */
+struct _rt_kdtree_device;
+int  rt_hip_adopt_tree( rt_hip_ctx *c, struct _rt_kdtree_device *t );
+/* build on the context's device and stream from HOST geometry and install the result */
+int  rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, int maxDepth, int maxPrims );
 int  rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n );
 int  rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n );
 int  rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n );

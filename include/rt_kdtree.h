@@ -65,6 +65,34 @@ int  rt_kdtree_flatten( const rt_cl_kdtree_node *nodes, uint64_t nodesCount, con
 	uint64_t primsIdxCount, const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, const rt_box *bbox, rt_kdtree_flat *out );
 
+/*
+ * The same builder on the GPU (no reference counterpart; same tree, bit for
+ * bit, as rt_kdtree_build_flat for the same limits).  verts / tris are HOST
+ * arrays as the reference API hands them over; the tree is left in DEVICE
+ * memory (hipMalloc) in the layout of rt_hip.h, recs with one spare record at
+ * the end.  rt_hip_adopt_tree (rt_hip.h) installs it in a context without a
+ * copy; rt_kdtree_device_release frees a tree that was not adopted.
+ */
+typedef struct _rt_kdtree_device
+{
+	void *nodes;   uint64_t nNodes;      /* rt_hip_kdnode   */
+	void *recs;    uint64_t nRecs;       /* rt_hip_trirec, nRecs + 1 entries allocated */
+	void *shade;   uint64_t nTris;       /* rt_hip_trishade */
+	rt_box bbox;
+	int depth;
+	uint32_t maxMaterial;                /* highest material slot any triangle references */
+} rt_kdtree_device;
+
+/* Returns 0 on success (1 bad arguments, 2 limits, 3 vertex index out of
+ * range, 4 tree too large for 30-bit links, 10 HIP failure, see
+ * rt_kdtree_device_last_error).  hipStream: stream to build on, NULL = default. */
+int  rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, int maxDepth, int maxPrims, void *hipStream, rt_kdtree_device *out );
+void rt_kdtree_device_release( rt_kdtree_device *t );
+/* copy a device tree to host arrays (malloc'ed; rt_kdtree_flat_release frees them) */
+int  rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_flat *out );
+const char *rt_kdtree_device_last_error( void );
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,13 @@ class FlatTree(C.Structure):      # rt_kdtree_flat
                 ("bbox", C.c_float * 8), ("depth", C.c_int)]
 
 
+class DeviceTreeStruct(C.Structure):   # rt_kdtree_device
+    _fields_ = [("nodes", C.c_void_p), ("nNodes", C.c_uint64),
+                ("recs", C.c_void_p), ("nRecs", C.c_uint64),
+                ("shade", C.c_void_p), ("nTris", C.c_uint64),
+                ("bbox", C.c_float * 8), ("depth", C.c_int), ("maxMaterial", C.c_uint32)]
+
+
 class BuildOpts(C.Structure):     # rt_kdtree_build_opts
     _fields_ = [("maxDepth", C.c_int), ("maxPrims", C.c_int), ("threads", C.c_int),
                 ("sahStop", C.c_float), ("allAxes", C.c_int)]

@@ -1,0 +1,739 @@
+// kd-tree builder on the GPU (gfx950): the same tree as the host builder
+// (kd_build.cpp, i.e. the reference's rule, rt_funcs_render_pipe.c:591-1209),
+// produced level by level in HBM and emitted directly in the layout the
+// traversal kernels read, so a rebuilt tree never crosses PCIe.
+//
+// One level = the set of nodes of one depth.  Per level:
+//   k_decide    node  : leaf (count <= maxPrims or depth == maxDepth) or split axis + candidate planes
+//   k_hist      ref   : histogram of every triangle extent against the 32 planes of its node
+//   k_split     node  : counts left / right of every plane, SAH cost, lowest-index minimum
+//   scans       node  : child node numbers, child reference ranges, leaf pool ranges (hipCUB)
+//   k_children  node  : child boxes, next level's node table, this node's record of the tree
+//   k_flags + scan + k_scatter  ref : STABLE partition of the triangle references
+//                       (a reference goes left if min < sep, right if max > sep, possibly both)
+// then, over the finished tree: sub-tree sizes bottom-up, pre-order positions
+// top-down (left child = own index + 1), nodes + leaf records + shading records.
+//
+// fp32 expressions are the host builder's, operand for operand, and the file
+// is compiled with -ffp-contract=off: the result is the host tree bit for bit
+// (tests/test_kdtree_gpu.py).  The host drives the level loop and reads three
+// totals per level to size the next one.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rt_kdtree.h"
+
+namespace {
+
+constexpr int PARTS = SAH_PARTS;
+constexpr int TB = 256;
+
+#define GCHK( x ) do { hipError_t e_ = ( x ); if ( e_ != hipSuccess ) { \
+	snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "%s failed: %s (%s:%d)", #x, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
+	return 10; } } while ( 0 )
+
+thread_local char g_gpu_build_err[512] = "";
+
+// device buffer that grows (contents are NOT kept unless keep > 0)
+struct DVec
+{
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve( size_t bytes, hipStream_t s, size_t keep = 0 )
+	{
+		if ( bytes <= cap )
+			return 0;
+		size_t want = bytes + bytes / 2 + 4096;
+		void *q = nullptr;
+		GCHK( hipMalloc( &q, want ) );
+		if ( keep && p )
+			GCHK( hipMemcpyAsync( q, p, keep, hipMemcpyDeviceToDevice, s ) );
+		if ( p )
+		{
+			GCHK( hipStreamSynchronize( s ) );
+			GCHK( hipFree( p ) );
+		}
+		p = q;
+		cap = want;
+		return 0;
+	}
+	void release() { if ( p ) (void) hipFree( p ); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T *) p; }
+};
+
+// ---- per-triangle extents: the compare chain of rt_funcs_render_pipe.c:620-633
+__device__ inline void tri_extent( float a, float b, float c, float &mn, float &mx )
+{
+	mx = a;
+	if ( mx < b ) mx = b;
+	if ( mx < c ) mx = c;
+	mn = a;
+	if ( mn > b ) mn = b;
+	if ( mn > c ) mn = c;
+}
+
+__global__ __launch_bounds__( TB ) void k_extents( const rt_vertex *verts, const rt_triangle *tris, uint32_t nT, float *ext )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i >= nT )
+		return;
+	const rt_vector3 p0 = verts[tris[i].pV0].pos, p1 = verts[tris[i].pV1].pos, p2 = verts[tris[i].pV2].pos;
+	tri_extent( p0.x, p1.x, p2.x, ext[i], ext[3ull * nT + i] );
+	tri_extent( p0.y, p1.y, p2.y, ext[(size_t) nT + i], ext[4ull * nT + i] );
+	tri_extent( p0.z, p1.z, p2.z, ext[2ull * nT + i], ext[5ull * nT + i] );
+}
+
+__global__ __launch_bounds__( TB ) void k_iota( uint32_t *refs, uint32_t *refNode, uint32_t n )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i < n )
+	{
+		refs[i] = i;
+		refNode[i] = 0u;
+	}
+}
+
+// ---- level tables (one entry per node of the level) ----------------------
+struct LevelTab
+{
+	float *box;            // [6 * n]: centre xyz, half extent xyz
+	uint32_t *start, *count;
+};
+
+struct NodeWork            // per node of the current level
+{
+	uint32_t *split;       // 1 = inner node
+	uint32_t *axis;
+	uint32_t *sorted;      // candidate planes ascending (always, except for NaN / inverted boxes)
+	float *mn, *delta;
+	uint32_t *hist;        // [66 * n]: sorted: histL[33], histR[33]; else L[32], R[32] directly
+	float *sep;
+	uint32_t *cntL, *cntR;
+	uint32_t *childRefs, *leafCnt;
+	uint32_t *splitIdx, *childStart, *leafStart;    // exclusive scans of split / childRefs / leafCnt
+};
+
+__device__ inline float box_c( const float *b, int ax ) { return b[ax]; }
+__device__ inline float box_e( const float *b, int ax ) { return b[3 + ax]; }
+
+__global__ __launch_bounds__( TB ) void k_decide( LevelTab L, NodeWork W, uint32_t n, int depth, int maxDepth, int maxPrims )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i >= n )
+		return;
+	const float *b = L.box + 6ull * i;
+	const uint32_t cnt = L.count[i];
+	for ( int k = 0; k < 66; ++k )
+		W.hist[66ull * i + k] = 0u;
+	if ( cnt <= (uint32_t) maxPrims || depth == maxDepth )
+	{
+		W.split[i] = 0u;
+		W.leafCnt[i] = cnt;
+		W.childRefs[i] = 0u;
+		return;
+	}
+	// longest half extent, ties X > Y > Z (:945-957)
+	float range = b[3];
+	int ax = 0;
+	if ( range < b[4] ) { range = b[4]; ax = 1; }
+	if ( range < b[5] ) { range = b[5]; ax = 2; }
+	const float c = box_c( b, ax ), e = box_e( b, ax );
+	const float mn = c - e, mx = c + e;
+	const float delta = ( mx - mn ) / (float) PARTS;
+	bool sorted = true;
+	float prev = 0.0f;
+	for ( int k = 0; k < PARTS; ++k )
+	{
+		const float s = mn + k * delta;
+		if ( k && !( prev <= s ) ) sorted = false;
+		prev = s;
+	}
+	W.split[i] = 1u;
+	W.leafCnt[i] = 0u;
+	W.axis[i] = (uint32_t) ax;
+	W.sorted[i] = sorted ? 1u : 0u;
+	W.mn[i] = mn;
+	W.delta[i] = delta;
+}
+
+// Counting goes through a histogram in LDS for the node the block's first
+// reference belongs to (near the root a node spans thousands of blocks, and
+// atomics of all of them on the same 66 words of HBM would be executed one
+// after the other); references of other nodes inside the block count directly.
+__global__ __launch_bounds__( TB ) void k_hist( NodeWork W, const uint32_t *refs, const uint32_t *refNode, uint32_t nRefs,
+	const float *ext, uint32_t nT )
+{
+	__shared__ uint32_t sh[66];
+	const uint32_t j = blockIdx.x * TB + threadIdx.x;
+	const uint32_t node0 = refNode[blockIdx.x * TB];
+	if ( threadIdx.x < 66 )
+		sh[threadIdx.x] = 0u;
+	__syncthreads();
+	if ( j < nRefs )
+	{
+		const uint32_t i = refNode[j];
+		if ( W.split[i] )
+		{
+			const uint32_t ax = W.axis[i], tri = refs[j];
+			const float a = ext[(size_t) ax * nT + tri], b = ext[( 3ull + ax ) * nT + tri];
+			const float mn = W.mn[i], delta = W.delta[i];
+			uint32_t *h = i == node0 ? sh : W.hist + 66ull * i;
+			if ( W.sorted[i] )
+			{
+				// lo = number of planes at or below the triangle's minimum, hi = number of planes below its maximum
+				int lo = 0, hi = 0;
+				for ( int step = PARTS / 2; step; step >>= 1 )
+				{
+					if ( !( a < mn + ( lo + step - 1 ) * delta ) ) lo += step;
+					if ( b > mn + ( hi + step - 1 ) * delta ) hi += step;
+				}
+				if ( lo < PARTS && !( a < mn + lo * delta ) ) ++lo;
+				if ( hi < PARTS && b > mn + hi * delta ) ++hi;
+				atomicAdd( &h[lo], 1u );
+				atomicAdd( &h[33 + hi], 1u );
+			}
+			else
+			{
+				for ( int k = 0; k < PARTS; ++k )
+				{
+					const float s = mn + k * delta;
+					if ( a < s ) atomicAdd( &h[k], 1u );
+					if ( b > s ) atomicAdd( &h[33 + k], 1u );
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if ( threadIdx.x < 66 && sh[threadIdx.x] )
+		atomicAdd( &W.hist[66ull * node0 + threadIdx.x], sh[threadIdx.x] );
+}
+
+// SAH sweep of :591-857 on the counts: lowest index with the strictly smallest cost
+__global__ __launch_bounds__( TB ) void k_split( LevelTab L, NodeWork W, uint32_t n )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i >= n || !W.split[i] )
+		return;
+	const float *b = L.box + 6ull * i;
+	const int ax = (int) W.axis[i];
+	const float c = box_c( b, ax ), e = box_e( b, ax );
+	const float mn = W.mn[i], delta = W.delta[i];
+	float eA, eB;
+	if ( ax == 0 ) { eA = b[4]; eB = b[5]; }
+	else if ( ax == 1 ) { eA = b[3]; eB = b[5]; }
+	else { eA = b[3]; eB = b[4]; }
+	const float area = eA * eB;
+	const uint32_t *h = W.hist + 66ull * i;
+	const bool sorted = W.sorted[i] != 0u;
+
+	// R[k] needs a suffix sum: total first
+	unsigned long long accR = 0;
+	if ( sorted )
+		for ( int k = 1; k <= PARTS; ++k ) accR += h[33 + k];
+	unsigned long long accL = 0;
+	float best = 0.0f, outSep = 0.0f;
+	unsigned long long cl = 0, cr = 0;
+	for ( int k = 0; k < PARTS; ++k )
+	{
+		unsigned long long Lk, Rk;
+		if ( sorted )
+		{
+			accL += h[k];
+			Lk = accL;
+			Rk = accR;               // sum of histR[k+1 .. 32]
+			accR -= h[33 + k + 1];
+		}
+		else
+		{
+			Lk = h[k];
+			Rk = h[33 + k];
+		}
+		const float sep = mn + k * delta;
+		const float sah = ( area + ( sep - c + e ) * ( eA + eB ) ) * Lk + ( area + ( c + e - sep ) * ( eA + eB ) ) * Rk;
+		if ( k == 0 || sah < best )
+		{
+			best = sah;
+			outSep = sep;
+			cl = Lk;
+			cr = Rk;
+		}
+	}
+	W.sep[i] = outSep;
+	W.cntL[i] = (uint32_t) cl;
+	W.cntR[i] = (uint32_t) cr;
+	W.childRefs[i] = (uint32_t) ( cl + cr );
+}
+
+// totals of the three scans -> host (3 words)
+__global__ void k_totals( NodeWork W, uint32_t n, uint32_t *out )
+{
+	if ( threadIdx.x == 0 && blockIdx.x == 0 )
+	{
+		out[0] = W.splitIdx[n - 1] + W.split[n - 1];
+		out[1] = W.childStart[n - 1] + W.childRefs[n - 1];
+		out[2] = W.leafStart[n - 1] + W.leafCnt[n - 1];
+	}
+}
+
+// child boxes: slab split at sep (:1034-1073); record of the node in level order
+__global__ __launch_bounds__( TB ) void k_children( LevelTab L, NodeWork W, LevelTab N, uint32_t n, uint2 *info, uint32_t idBase,
+	uint32_t nextBase, uint32_t leafPoolBase )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i >= n )
+		return;
+	if ( !W.split[i] )
+	{
+		info[idBase + i] = make_uint2( leafPoolBase + W.leafStart[i], ( L.count[i] << 2 ) | 3u );
+		return;
+	}
+	const float *b = L.box + 6ull * i;
+	const int ax = (int) W.axis[i];
+	const float sep = W.sep[i];
+	const uint32_t c = 2u * W.splitIdx[i];
+	float *bl = N.box + 6ull * c, *br = bl + 6;
+	for ( int k = 0; k < 6; ++k )
+		bl[k] = br[k] = b[k];
+	bl[ax] = 0.5f * ( box_c( b, ax ) - box_e( b, ax ) + sep );
+	bl[3 + ax] = 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) );
+	br[ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep );
+	br[3 + ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep );
+	N.start[c] = W.childStart[i];
+	N.count[c] = W.cntL[i];
+	N.start[c + 1] = W.childStart[i] + W.cntL[i];
+	N.count[c + 1] = W.cntR[i];
+	info[idBase + i] = make_uint2( __float_as_uint( sep ), ( ( nextBase + c ) << 2 ) | (uint32_t) ax );
+}
+
+// per reference: goes left (low word) / right (high word)
+__global__ __launch_bounds__( TB ) void k_flags( NodeWork W, const uint32_t *refs, const uint32_t *refNode, uint32_t nRefs,
+	const float *ext, uint32_t nT, unsigned long long *flags )
+{
+	const uint32_t j = blockIdx.x * TB + threadIdx.x;
+	if ( j >= nRefs )
+		return;
+	const uint32_t i = refNode[j];
+	unsigned long long f = 0ull;
+	if ( W.split[i] )
+	{
+		const uint32_t ax = W.axis[i], tri = refs[j];
+		const float sep = W.sep[i];
+		if ( ext[(size_t) ax * nT + tri] < sep ) f |= 1ull;
+		if ( ext[( 3ull + ax ) * nT + tri] > sep ) f |= 1ull << 32;
+	}
+	flags[j] = f;
+}
+
+// stable partition (:971-1029): the k-th reference of a node that goes left
+// becomes the k-th reference of its left child; leaves move to the leaf pool
+__global__ __launch_bounds__( TB ) void k_scatter( LevelTab L, NodeWork W, const uint32_t *refs, const uint32_t *refNode, uint32_t nRefs,
+	const unsigned long long *flags, const unsigned long long *scan, uint32_t *nextRefs, uint32_t *nextRefNode,
+	uint32_t *leafPool, uint32_t leafPoolBase )
+{
+	const uint32_t j = blockIdx.x * TB + threadIdx.x;
+	if ( j >= nRefs )
+		return;
+	const uint32_t i = refNode[j], tri = refs[j], s0 = L.start[i];
+	if ( !W.split[i] )
+	{
+		leafPool[leafPoolBase + W.leafStart[i] + ( j - s0 )] = tri;
+		return;
+	}
+	const unsigned long long f = flags[j], here = scan[j], base = scan[s0];
+	const uint32_t c = 2u * W.splitIdx[i];
+	if ( f & 1ull )
+	{
+		const uint32_t p = W.childStart[i] + ( (uint32_t) here - (uint32_t) base );
+		nextRefs[p] = tri;
+		nextRefNode[p] = c;
+	}
+	if ( f >> 32 )
+	{
+		const uint32_t p = W.childStart[i] + W.cntL[i] + ( (uint32_t) ( here >> 32 ) - (uint32_t) ( base >> 32 ) );
+		nextRefs[p] = tri;
+		nextRefNode[p] = c + 1u;
+	}
+}
+
+// ---- finished tree: sizes, positions, output --------------------------------
+__global__ __launch_bounds__( TB ) void k_sizes( const uint2 *info, uint32_t first, uint32_t n, uint32_t *subNodes, uint32_t *subRefs, uint32_t *subDepth )
+{
+	const uint32_t k = blockIdx.x * TB + threadIdx.x;
+	if ( k >= n )
+		return;
+	const uint32_t id = first + k;
+	const uint2 v = info[id];
+	if ( ( v.y & 3u ) == 3u )
+	{
+		subNodes[id] = 1u;
+		subRefs[id] = v.y >> 2;
+		subDepth[id] = 0u;
+		return;
+	}
+	const uint32_t l = v.y >> 2;
+	subNodes[id] = 1u + subNodes[l] + subNodes[l + 1];
+	subRefs[id] = subRefs[l] + subRefs[l + 1];
+	subDepth[id] = 1u + ( subDepth[l] > subDepth[l + 1] ? subDepth[l] : subDepth[l + 1] );
+}
+
+// pre-order numbering, left child right behind its parent (:860-912)
+__global__ __launch_bounds__( TB ) void k_positions( const uint2 *info, uint32_t first, uint32_t n, const uint32_t *subNodes, const uint32_t *subRefs,
+	uint32_t *pos, uint32_t *refPos )
+{
+	const uint32_t k = blockIdx.x * TB + threadIdx.x;
+	if ( k >= n )
+		return;
+	const uint32_t id = first + k;
+	const uint2 v = info[id];
+	if ( ( v.y & 3u ) == 3u )
+		return;
+	const uint32_t l = v.y >> 2;
+	pos[l] = pos[id] + 1u;
+	pos[l + 1] = pos[id] + 1u + subNodes[l];
+	refPos[l] = refPos[id];
+	refPos[l + 1] = refPos[id] + subRefs[l];
+}
+
+__global__ __launch_bounds__( TB ) void k_emit( const uint2 *info, uint32_t n, const uint32_t *pos, const uint32_t *refPos, const uint32_t *leafPool,
+	rt_hip_kdnode *nodes, uint32_t *order )
+{
+	const uint32_t id = blockIdx.x * TB + threadIdx.x;
+	if ( id >= n )
+		return;
+	const uint2 v = info[id];
+	rt_hip_kdnode o;
+	if ( ( v.y & 3u ) == 3u )
+	{
+		const uint32_t cnt = v.y >> 2, dst = refPos[id];
+		o.a = dst;
+		o.b = v.y;
+		for ( uint32_t k = 0; k < cnt; ++k )
+			order[dst + k] = leafPool[v.x + k];
+	}
+	else
+	{
+		o.a = v.x;
+		o.b = ( pos[( v.y >> 2 ) + 1u] << 2 ) | ( v.y & 3u );
+	}
+	nodes[pos[id]] = o;
+}
+
+__global__ __launch_bounds__( TB ) void k_records( const rt_vertex *verts, const rt_triangle *tris, const uint32_t *order, uint32_t nRecs, rt_hip_trirec *recs )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i > nRecs )
+		return;
+	rt_hip_trirec r;
+	memset( &r, 0, sizeof( r ) );
+	if ( i < nRecs )              // entry nRecs is the zeroed spare record the look-ahead load may touch
+	{
+		const rt_triangle t = tris[order[i]];
+		const rt_vector3 p0 = verts[t.pV0].pos, p1 = verts[t.pV1].pos, p2 = verts[t.pV2].pos;
+		r.nv0x = -p0.x; r.nv0y = -p0.y; r.nv0z = -p0.z;
+		r.e1x = p1.x - p0.x; r.e1y = p1.y - p0.y; r.e1z = p1.z - p0.z;
+		r.e2x = p2.x - p0.x; r.e2y = p2.y - p0.y; r.e2z = p2.z - p0.z;
+		r.tri = order[i];
+		r.mat = (uint32_t) t.mat;
+	}
+	recs[i] = r;
+}
+
+__global__ __launch_bounds__( TB ) void k_shade_records( const rt_vertex *verts, const rt_triangle *tris, uint32_t nT, rt_hip_trishade *shade )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i >= nT )
+		return;
+	const rt_triangle t = tris[i];
+	const rt_vector3 n0 = verts[t.pV0].norm, n1 = verts[t.pV1].norm, n2 = verts[t.pV2].norm;
+	rt_hip_trishade s;
+	s.n0[0] = n0.x; s.n0[1] = n0.y; s.n0[2] = n0.z;
+	s.n1[0] = n1.x; s.n1[1] = n1.y; s.n1[2] = n1.z;
+	s.n2[0] = n2.x; s.n2[1] = n2.y; s.n2[2] = n2.z;
+	s.mat = (uint32_t) t.mat;
+	s._pad[0] = s._pad[1] = 0;
+	shade[i] = s;
+}
+
+inline unsigned grid_of( size_t n ) { return (unsigned) ( ( n + TB - 1 ) / TB ); }
+
+// scene box on the host, :1114-1137 (the vertices are host data)
+void scene_box( const rt_vertex *verts, uint64_t n, rt_box &bbox )
+{
+	float mnx = 0, mny = 0, mnz = 0, mxx = 0, mxy = 0, mxz = 0;
+	for ( uint64_t i = 0; i < n; ++i )
+	{
+		const rt_vector3 &p = verts[i].pos;
+		mnx = ( mnx > p.x || i == 0 ) ? p.x : mnx;
+		mny = ( mny > p.y || i == 0 ) ? p.y : mny;
+		mnz = ( mnz > p.z || i == 0 ) ? p.z : mnz;
+		mxx = ( mxx < p.x || i == 0 ) ? p.x : mxx;
+		mxy = ( mxy < p.y || i == 0 ) ? p.y : mxy;
+		mxz = ( mxz < p.z || i == 0 ) ? p.z : mxz;
+	}
+	mnx -= 1.0f; mny -= 1.0f; mnz -= 1.0f;
+	mxx += 1.0f; mxy += 1.0f; mxz += 1.0f;
+	memset( &bbox, 0, sizeof( bbox ) );
+	bbox.center.x = ( mnx + mxx ) * 0.5f;
+	bbox.center.y = ( mny + mxy ) * 0.5f;
+	bbox.center.z = ( mnz + mxz ) * 0.5f;
+	bbox.extents.x = ( mxx - mnx ) * 0.5f;
+	bbox.extents.y = ( mxy - mny ) * 0.5f;
+	bbox.extents.z = ( mxz - mnz ) * 0.5f;
+}
+
+struct Scratch
+{
+	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, flags, scan, cub, info, leafPool, work, sub, order;
+	void release()
+	{
+		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &flags, &scan, &cub, &info, &leafPool, &work, &sub, &order } )
+			v->release();
+	}
+};
+
+// carve the per-level node tables out of one allocation
+int level_tab( DVec &buf, size_t n, hipStream_t s, LevelTab &t )
+{
+	if ( n == 0 ) n = 1;
+	if ( int rc = buf.reserve( n * ( 6 * sizeof( float ) + 2 * sizeof( uint32_t ) ), s ) ) return rc;
+	t.box = buf.as<float>();
+	t.start = (uint32_t *) ( t.box + 6 * n );
+	t.count = t.start + n;
+	return 0;
+}
+
+int node_work( DVec &buf, size_t n, hipStream_t s, NodeWork &w )
+{
+	if ( n == 0 ) n = 1;
+	if ( int rc = buf.reserve( n * ( 66 + 14 ) * sizeof( uint32_t ), s ) ) return rc;
+	uint32_t *p = buf.as<uint32_t>();
+	w.hist = p; p += 66 * n;
+	w.split = p; p += n;
+	w.axis = p; p += n;
+	w.sorted = p; p += n;
+	w.mn = (float *) p; p += n;
+	w.delta = (float *) p; p += n;
+	w.sep = (float *) p; p += n;
+	w.cntL = p; p += n;
+	w.cntR = p; p += n;
+	w.childRefs = p; p += n;
+	w.leafCnt = p; p += n;
+	w.splitIdx = p; p += n;
+	w.childStart = p; p += n;
+	w.leafStart = p; p += n;
+	return 0;
+}
+
+template <class T>
+int exclusive_sum( DVec &cub, const T *in, T *out, size_t n, hipStream_t s )
+{
+	size_t bytes = 0;
+	GCHK( hipcub::DeviceScan::ExclusiveSum( nullptr, bytes, in, out, (int) n, s ) );
+	if ( int rc = cub.reserve( bytes ? bytes : 16, s ) ) return rc;
+	GCHK( hipcub::DeviceScan::ExclusiveSum( cub.p, bytes, in, out, (int) n, s ) );
+	return 0;
+}
+
+} // namespace
+
+extern "C" const char *rt_kdtree_device_last_error( void ) { return g_gpu_build_err; }
+
+extern "C" void rt_kdtree_device_release( rt_kdtree_device *t )
+{
+	if ( !t )
+		return;
+	if ( t->nodes ) (void) hipFree( t->nodes );
+	if ( t->recs ) (void) hipFree( t->recs );
+	if ( t->shade ) (void) hipFree( t->shade );
+	memset( t, 0, sizeof( *t ) );
+}
+
+extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, int maxDepth, int maxPrims, void *hipStream, rt_kdtree_device *out )
+{
+	g_gpu_build_err[0] = 0;
+	if ( !out || ( vertexCount && !verts ) || ( trianglesCount && !tris ) )
+		return 1;
+	if ( trianglesCount >= ( 1ull << 30 ) || maxDepth < 0 || maxDepth > RT_HIP_MAX_TREE_DEPTH || maxPrims < 1 )
+		return 2;
+	uint32_t maxMat = 0;
+	for ( uint64_t i = 0; i < trianglesCount; ++i )
+	{
+		if ( tris[i].pV0 >= vertexCount || tris[i].pV1 >= vertexCount || tris[i].pV2 >= vertexCount )
+			return 3;
+		if ( tris[i].mat > maxMat ) maxMat = (uint32_t) tris[i].mat;
+	}
+	memset( out, 0, sizeof( *out ) );
+	hipStream_t s = (hipStream_t) hipStream;
+	const uint32_t nT = (uint32_t) trianglesCount;
+	scene_box( verts, vertexCount, out->bbox );
+	out->maxMaterial = maxMat;
+
+	Scratch S;
+	struct Guard { Scratch &s; ~Guard() { s.release(); } } guard{ S };
+
+	// inputs
+	if ( int rc = S.verts.reserve( sizeof( rt_vertex ) * ( vertexCount ? vertexCount : 1 ), s ) ) return rc;
+	if ( int rc = S.tris.reserve( sizeof( rt_triangle ) * ( nT ? nT : 1 ), s ) ) return rc;
+	if ( vertexCount ) GCHK( hipMemcpyAsync( S.verts.p, verts, sizeof( rt_vertex ) * vertexCount, hipMemcpyHostToDevice, s ) );
+	if ( nT ) GCHK( hipMemcpyAsync( S.tris.p, tris, sizeof( rt_triangle ) * nT, hipMemcpyHostToDevice, s ) );
+	if ( int rc = S.ext.reserve( 6 * sizeof( float ) * ( nT ? nT : 1 ), s ) ) return rc;
+	if ( nT ) hipLaunchKernelGGL( k_extents, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT, S.ext.as<float>() );
+
+	// level 0: the root holds every triangle in index order
+	DVec *refsCur = &S.refsA, *refsNext = &S.refsB, *tabCur = &S.nodeA, *tabNext = &S.nodeB;
+	if ( int rc = refsCur->reserve( 2 * sizeof( uint32_t ) * ( nT ? nT : 1 ), s ) ) return rc;
+	size_t refCap = refsCur->cap / ( 2 * sizeof( uint32_t ) );
+	uint32_t *refs = refsCur->as<uint32_t>(), *refNode = refs + refCap;
+	if ( nT ) hipLaunchKernelGGL( k_iota, dim3( grid_of( nT ) ), dim3( TB ), 0, s, refs, refNode, nT );
+	LevelTab cur;
+	if ( int rc = level_tab( *tabCur, 1, s, cur ) ) return rc;
+	{
+		const float rootBox[6] = { out->bbox.center.x, out->bbox.center.y, out->bbox.center.z,
+			out->bbox.extents.x, out->bbox.extents.y, out->bbox.extents.z };
+		const uint32_t se[2] = { 0u, nT };
+		GCHK( hipMemcpyAsync( cur.box, rootBox, sizeof( rootBox ), hipMemcpyHostToDevice, s ) );
+		GCHK( hipMemcpyAsync( cur.start, &se[0], 4, hipMemcpyHostToDevice, s ) );
+		GCHK( hipMemcpyAsync( cur.count, &se[1], 4, hipMemcpyHostToDevice, s ) );
+		GCHK( hipStreamSynchronize( s ) );
+	}
+
+	uint32_t *hTotals = nullptr;
+	GCHK( hipHostMalloc( (void **) &hTotals, 3 * sizeof( uint32_t ), hipHostMallocDefault ) );
+	struct HostGuard { uint32_t *p; ~HostGuard() { (void) hipHostFree( p ); } } hostGuard{ hTotals };
+	DVec totalsDev;
+	if ( int rc = totalsDev.reserve( 16, s ) ) return rc;
+	struct DevGuard { DVec &v; ~DevGuard() { v.release(); } } devGuard{ totalsDev };
+
+	std::vector<uint32_t> levelFirst, levelCount;
+	uint64_t nodesTotal = 0, leafRefs = 0;
+	uint32_t levelNodes = 1, levelRefs = nT;
+	for ( int depth = 0; ; ++depth )
+	{
+		levelFirst.push_back( (uint32_t) nodesTotal );
+		levelCount.push_back( levelNodes );
+		if ( nodesTotal + levelNodes >= ( 1ull << 30 ) )
+			return 4;
+		NodeWork W;
+		if ( int rc = node_work( S.work, levelNodes, s, W ) ) return rc;
+		if ( int rc = S.info.reserve( sizeof( uint2 ) * ( nodesTotal + levelNodes ), s, sizeof( uint2 ) * nodesTotal ) ) return rc;
+
+		hipLaunchKernelGGL( k_decide, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, levelNodes, depth, maxDepth, maxPrims );
+		if ( levelRefs )
+			hipLaunchKernelGGL( k_hist, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, W, refs, refNode, levelRefs, S.ext.as<float>(), nT );
+		hipLaunchKernelGGL( k_split, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, levelNodes );
+		if ( int rc = exclusive_sum( S.cub, W.split, W.splitIdx, levelNodes, s ) ) return rc;
+		if ( int rc = exclusive_sum( S.cub, W.childRefs, W.childStart, levelNodes, s ) ) return rc;
+		if ( int rc = exclusive_sum( S.cub, W.leafCnt, W.leafStart, levelNodes, s ) ) return rc;
+		hipLaunchKernelGGL( k_totals, dim3( 1 ), dim3( 64 ), 0, s, W, levelNodes, totalsDev.as<uint32_t>() );
+		GCHK( hipMemcpyAsync( hTotals, totalsDev.p, 3 * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+		GCHK( hipStreamSynchronize( s ) );
+		const uint32_t splits = hTotals[0], childRefs = hTotals[1], levelLeafRefs = hTotals[2];
+		if ( (uint64_t) splits * 2 + nodesTotal + levelNodes >= ( 1ull << 30 ) || leafRefs + levelLeafRefs + childRefs >= ( 1ull << 30 ) )
+			return 4;          // 30-bit links of the 8-byte node
+
+		// next level's tables and reference arrays, leaf pool
+		LevelTab next;
+		if ( int rc = level_tab( *tabNext, 2 * (size_t) splits, s, next ) ) return rc;
+		if ( int rc = refsNext->reserve( 2 * sizeof( uint32_t ) * ( childRefs ? childRefs : 1 ), s ) ) return rc;
+		const size_t nextCap = refsNext->cap / ( 2 * sizeof( uint32_t ) );
+		uint32_t *nRefs = refsNext->as<uint32_t>(), *nRefNode = nRefs + nextCap;
+		if ( int rc = S.leafPool.reserve( sizeof( uint32_t ) * ( leafRefs + levelLeafRefs + 1 ), s, sizeof( uint32_t ) * leafRefs ) ) return rc;
+
+		hipLaunchKernelGGL( k_children, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, next, levelNodes, S.info.as<uint2>(),
+			(uint32_t) nodesTotal, (uint32_t) ( nodesTotal + levelNodes ), (uint32_t) leafRefs );
+		if ( levelRefs )
+		{
+			if ( int rc = S.flags.reserve( sizeof( unsigned long long ) * levelRefs, s ) ) return rc;
+			if ( int rc = S.scan.reserve( sizeof( unsigned long long ) * levelRefs, s ) ) return rc;
+			hipLaunchKernelGGL( k_flags, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, W, refs, refNode, levelRefs, S.ext.as<float>(), nT,
+				S.flags.as<unsigned long long>() );
+			if ( int rc = exclusive_sum( S.cub, S.flags.as<unsigned long long>(), S.scan.as<unsigned long long>(), levelRefs, s ) ) return rc;
+			hipLaunchKernelGGL( k_scatter, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, cur, W, refs, refNode, levelRefs,
+				S.flags.as<unsigned long long>(), S.scan.as<unsigned long long>(), nRefs, nRefNode, S.leafPool.as<uint32_t>(), (uint32_t) leafRefs );
+		}
+
+		nodesTotal += levelNodes;
+		leafRefs += levelLeafRefs;
+		if ( splits == 0 )
+			break;
+		std::swap( refsCur, refsNext );
+		std::swap( tabCur, tabNext );
+		cur = next;
+		refs = nRefs;
+		refNode = nRefNode;
+		levelNodes = 2 * splits;
+		levelRefs = childRefs;
+	}
+
+	// sizes bottom-up, positions top-down
+	const uint32_t nNodes = (uint32_t) nodesTotal;
+	if ( int rc = S.sub.reserve( 5 * sizeof( uint32_t ) * (size_t) nNodes, s ) ) return rc;
+	uint32_t *subNodes = S.sub.as<uint32_t>(), *subRefs = subNodes + nNodes, *subDepth = subRefs + nNodes, *pos = subDepth + nNodes, *refPos = pos + nNodes;
+	const uint2 *info = S.info.as<uint2>();
+	for ( int d = (int) levelFirst.size() - 1; d >= 0; --d )
+		hipLaunchKernelGGL( k_sizes, dim3( grid_of( levelCount[d] ) ), dim3( TB ), 0, s, info, levelFirst[d], levelCount[d], subNodes, subRefs, subDepth );
+	GCHK( hipMemsetAsync( pos, 0, sizeof( uint32_t ), s ) );
+	GCHK( hipMemsetAsync( refPos, 0, sizeof( uint32_t ), s ) );
+	for ( size_t d = 0; d < levelFirst.size(); ++d )
+		hipLaunchKernelGGL( k_positions, dim3( grid_of( levelCount[d] ) ), dim3( TB ), 0, s, info, levelFirst[d], levelCount[d], subNodes, subRefs, pos, refPos );
+	uint32_t rootDepth = 0;
+	GCHK( hipMemcpyAsync( &rootDepth, subDepth, sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+
+	// output buffers (owned by the caller from here on)
+	const uint32_t nRecs = (uint32_t) leafRefs;
+	GCHK( hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * (size_t) nNodes ) );
+	GCHK( hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( (size_t) nRecs + 1 ) ) );
+	GCHK( hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) ) );
+	if ( int rc = S.order.reserve( sizeof( uint32_t ) * ( (size_t) nRecs + 1 ), s ) ) { rt_kdtree_device_release( out ); return rc; }
+	hipLaunchKernelGGL( k_emit, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, info, nNodes, pos, refPos, S.leafPool.as<uint32_t>(),
+		(rt_hip_kdnode *) out->nodes, S.order.as<uint32_t>() );
+	hipLaunchKernelGGL( k_records, dim3( grid_of( (size_t) nRecs + 1 ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(),
+		S.order.as<uint32_t>(), nRecs, (rt_hip_trirec *) out->recs );
+	if ( nT )
+		hipLaunchKernelGGL( k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
+			(rt_hip_trishade *) out->shade );
+	hipError_t e = hipGetLastError();
+	if ( e == hipSuccess ) e = hipStreamSynchronize( s );
+	if ( e != hipSuccess )
+	{
+		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "kd build kernels failed: %s", hipGetErrorString( e ) );
+		rt_kdtree_device_release( out );
+		return 10;
+	}
+	out->nNodes = nNodes;
+	out->nRecs = nRecs;
+	out->nTris = nT;
+	out->depth = (int) rootDepth;
+	return 0;
+}
+
+extern "C" int rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_flat *out )
+{
+	if ( !t || !out || !t->nodes )
+		return 1;
+	memset( out, 0, sizeof( *out ) );
+	out->nNodes = t->nNodes;
+	out->nRecs = t->nRecs;
+	out->nTris = t->nTris;
+	out->bbox = t->bbox;
+	out->depth = t->depth;
+	out->nodes = (rt_hip_kdnode *) malloc( sizeof( rt_hip_kdnode ) * ( t->nNodes ? t->nNodes : 1 ) );
+	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( t->nRecs ? t->nRecs : 1 ) );
+	out->shade = (rt_hip_trishade *) malloc( sizeof( rt_hip_trishade ) * ( t->nTris ? t->nTris : 1 ) );
+	hipError_t e = hipMemcpy( out->nodes, t->nodes, sizeof( rt_hip_kdnode ) * t->nNodes, hipMemcpyDeviceToHost );
+	if ( e == hipSuccess && t->nRecs ) e = hipMemcpy( out->recs, t->recs, sizeof( rt_hip_trirec ) * t->nRecs, hipMemcpyDeviceToHost );
+	if ( e == hipSuccess && t->nTris ) e = hipMemcpy( out->shade, t->shade, sizeof( rt_hip_trishade ) * t->nTris, hipMemcpyDeviceToHost );
+	if ( e != hipSuccess )
+	{
+		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "tree download failed: %s", hipGetErrorString( e ) );
+		rt_kdtree_flat_release( out );
+		return 10;
+	}
+	return 0;
+}

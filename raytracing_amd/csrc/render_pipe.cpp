@@ -28,7 +28,7 @@ struct rt_pipe_impl
 	std::vector<rt_material> mats;
 	rt_camera cam;
 	int maxDepth = MAX_DEPTH, maxPrims = MAX_PRIMS_IN_NODE, stackSize = STACK_SIZE;
-	int buildThreads = 0, treeCache = 0;
+	int buildThreads = 0, treeCache = 0, gpuBuild = 0;
 	int bandH = 16, nParts = 1, part = 0;
 	bool matsDirty = true;
 	bool haveTree = false;
@@ -289,6 +289,7 @@ void rt_render_pipe_set_param( rt_render_pipe *pRp, int key, int value )
 		break;
 	case RT_PARAM_BUILD_THREADS: im->buildThreads = value; break;
 	case RT_PARAM_TREE_CACHE: im->treeCache = value; break;
+	case RT_PARAM_GPU_BUILD: im->gpuBuild = value; im->haveTree = false; break;
 	case RT_PARAM_OVERLAP:
 		if ( rt_hip_set_param( im->hip, key, value ) )
 			die_hip( "rt_render_pipe_set_param" );
@@ -341,7 +342,17 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 	h = hash_bytes( im->tris.data(), im->tris.size() * sizeof( rt_triangle ), h );
 	const uint64_t bytes = im->verts.size() * sizeof( rt_vertex ) + im->tris.size() * sizeof( rt_triangle );
 	const bool reuse = im->treeCache && im->haveTree && h == im->geomHash && bytes == im->geomBytes;
-	if ( !reuse )
+	if ( !reuse && im->gpuBuild )
+	{
+		// same tree, built in HBM: nothing but the raw geometry crosses PCIe
+		if ( rt_hip_build_tree( im->hip, im->verts.data(), im->tris.data(), im->verts.size(), im->tris.size(),
+			im->maxDepth, im->maxPrims ) )
+			die_hip( "kd-tree build on the GPU" );
+		im->haveTree = true;
+		im->geomHash = h;
+		im->geomBytes = bytes;
+	}
+	else if ( !reuse )
 	{
 		rt_kdtree_flat t;
 		int rc = rt_kdtree_build_flat( im->verts.data(), im->tris.data(), im->verts.size(), im->tris.size(),

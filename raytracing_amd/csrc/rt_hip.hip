@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "rt_hip.h"
+#include "rt_kdtree.h"
 
 #define RT_BLOCK      256
 #ifndef RT_LDS_STACK
@@ -1604,6 +1605,54 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 	c->S.shade = (const float4 *) c->shade.p;
 	c->S.bbC[0] = bbox->center.x; c->S.bbC[1] = bbox->center.y; c->S.bbC[2] = bbox->center.z;
 	c->S.bbE[0] = bbox->extents.x; c->S.bbE[1] = bbox->extents.y; c->S.bbE[2] = bbox->extents.z;
+	return 0;
+}
+
+int rt_hip_adopt_tree( rt_hip_ctx *c, rt_kdtree_device *t )
+{
+	if ( !c || !t || !t->nodes || !t->recs || !t->shade || t->nNodes == 0 ) return fail( "rt_hip_adopt_tree: bad arguments" );
+	if ( t->depth > RT_HIP_MAX_TREE_DEPTH )
+		return fail( "rt_hip_adopt_tree: tree depth %d exceeds the traversal stack (%d)", t->depth, RT_HIP_MAX_TREE_DEPTH );
+	if ( t->nNodes >= ( 1ull << 30 ) || t->nRecs >= ( 1ull << 30 ) || t->nTris >= ( 1ull << 31 ) )
+		return fail( "rt_hip_adopt_tree: tree too large for 32-bit node links" );
+	HIPCHK( hipSetDevice( c->device ) );
+	// frames that still read the old tree must be done before it is freed
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	DevBuf *dst[3] = { &c->nodes, &c->recs, &c->shade };
+	void *src[3] = { t->nodes, t->recs, t->shade };
+	const size_t bytes[3] = { t->nNodes * sizeof( rt_hip_kdnode ), ( t->nRecs + 1 ) * sizeof( rt_hip_trirec ),
+		( t->nTris ? t->nTris : 1 ) * sizeof( rt_hip_trishade ) };
+	for ( int i = 0; i < 3; ++i )
+	{
+		if ( dst[i]->p ) HIPCHK( hipFree( dst[i]->p ) );
+		dst[i]->p = src[i];
+		dst[i]->cap = bytes[i];
+	}
+	c->maxMatTree = t->maxMaterial;
+	c->nNodes = t->nNodes; c->nRecs = t->nRecs; c->nTris = t->nTris; c->treeDepth = t->depth;
+	c->S.nodes = (const uint2 *) c->nodes.p;
+	c->S.recs = (const float4 *) c->recs.p;
+	c->S.shade = (const float4 *) c->shade.p;
+	c->S.bbC[0] = t->bbox.center.x; c->S.bbC[1] = t->bbox.center.y; c->S.bbC[2] = t->bbox.center.z;
+	c->S.bbE[0] = t->bbox.extents.x; c->S.bbE[1] = t->bbox.extents.y; c->S.bbE[2] = t->bbox.extents.z;
+	memset( t, 0, sizeof( *t ) );
+	return 0;
+}
+
+int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, int maxDepth, int maxPrims )
+{
+	if ( !c ) return fail( "null context" );
+	HIPCHK( hipSetDevice( c->device ) );
+	rt_kdtree_device t;
+	int rc = rt_kdtree_build_device( verts, tris, vertexCount, trianglesCount, maxDepth, maxPrims, c->stream, &t );
+	if ( rc )
+		return fail( "rt_hip_build_tree: builder returned %d (%s)", rc, rt_kdtree_device_last_error() );
+	if ( rt_hip_adopt_tree( c, &t ) )
+	{
+		rt_kdtree_device_release( &t );
+		return 1;
+	}
 	return 0;
 }
 

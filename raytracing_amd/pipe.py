@@ -14,11 +14,11 @@ import numpy as np
 
 from . import types as T
 from ._lib import FlatTree as _FlatTreeStruct
-from ._lib import RenderPipeStruct, RtError, Stats, check, lib
+from ._lib import DeviceTreeStruct, RenderPipeStruct, RtError, Stats, check, lib
 
 RT_HIP_STATS, RT_HIP_HITIDS, RT_HIP_TIMING = 1, 2, 4
 (RT_PARAM_STACK_SIZE, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
- RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE, RT_PARAM_OVERLAP) = 1, 2, 3, 4, 5, 6
+ RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE, RT_PARAM_OVERLAP, RT_PARAM_GPU_BUILD) = 1, 2, 3, 4, 5, 6, 7
 
 kdnode = np.dtype([("a", "<u4"), ("b", "<u4")])
 trirec = np.dtype([("nv0x", "<f4"), ("e1x", "<f4"), ("nv0y", "<f4"), ("e1y", "<f4"),
@@ -45,6 +45,52 @@ def _view(ptr, count, dtype):
         return np.zeros(0, dtype)
     buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
     return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class DeviceTree:
+    """kd-tree built on the GPU (rt_kdtree_device): lives in device memory
+    until a renderer adopts it or release() frees it."""
+
+    def __init__(self, struct):
+        self._s = struct
+
+    @classmethod
+    def build(cls, verts, tris, max_depth=10, max_prims=7, stream=None):
+        verts = np.ascontiguousarray(verts, T.vertex)
+        tris = np.ascontiguousarray(tris, T.triangle)
+        s = DeviceTreeStruct()
+        L = lib()
+        L.rt_kdtree_device_last_error.restype = C.c_char_p
+        rc = L.rt_kdtree_build_device(_p(verts), _p(tris), C.c_uint64(len(verts)), C.c_uint64(len(tris)),
+                                      C.c_int(max_depth), C.c_int(max_prims), C.c_void_p(stream), C.byref(s))
+        if rc:
+            raise RtError(f"rt_kdtree_build_device failed with code {rc}: {L.rt_kdtree_device_last_error().decode()}")
+        return cls(s)
+
+    @property
+    def n_nodes(self):
+        return int(self._s.nNodes)
+
+    @property
+    def n_recs(self):
+        return int(self._s.nRecs)
+
+    @property
+    def depth(self):
+        return int(self._s.depth)
+
+    def download(self):
+        """-> FlatTree copy on the host (for comparisons)."""
+        s = _FlatTreeStruct()
+        rc = lib().rt_kdtree_device_download(C.byref(self._s), C.byref(s))
+        if rc:
+            raise RtError(f"rt_kdtree_device_download failed with code {rc}")
+        return FlatTree(s)
+
+    def release(self):
+        if self._s is not None:
+            lib().rt_kdtree_device_release(C.byref(self._s))
+            self._s = None
 
 
 class FlatTree:
@@ -180,12 +226,20 @@ class HipRenderer:
     def local_rows(self):
         return self._L.rt_hip_local_rows(self._c)
 
+    def adopt_tree(self, dtree):
+        """Install a DeviceTree without a copy; the renderer owns its buffers afterwards."""
+        check(self._L.rt_hip_adopt_tree(self._c, C.byref(dtree._s)), "rt_hip_adopt_tree")
+        dtree._s = None
+
     def load_scene(self, scene, tree=None, max_depth=10, max_prims=7, threads=0):
         """Upload everything `scene` holds; builds the tree unless given. -> tree"""
         if tree is None:
             v, t = scene.flatten()
             tree = FlatTree.build(v, t, max_depth, max_prims, threads)
-        self.upload_tree(tree)
+        if isinstance(tree, DeviceTree):
+            self.adopt_tree(tree)
+        else:
+            self.upload_tree(tree)
         self.upload_materials(scene.material_table())
         self.upload_spheres(scene.sphere_table())
         self.upload_lights(scene.light_table())

@@ -1,0 +1,80 @@
+"""The GPU kd-tree builder against the host builder (which is pinned to the
+reference's own builder in test_kdtree.py): same tree, bit for bit."""
+import numpy as np
+import pytest
+
+from oracle.gen_golden import tree_scenes
+from raytracing_amd import scenes
+from raytracing_amd.pipe import RT_HIP_HITIDS, DeviceTree, FlatTree, HipRenderer
+from tests.helpers import random_soup
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_tree(v, t, depth, prims):
+    host = FlatTree.build(v, t, depth, prims, 4)
+    dev = DeviceTree.build(v, t, depth, prims)
+    got = dev.download()
+    assert (dev.n_nodes, dev.n_recs, dev.depth) == (len(host.nodes), len(host.recs), host.depth)
+    assert got.bbox.tobytes() == host.bbox.tobytes()
+    assert np.array_equal(got.nodes, host.nodes)
+    assert got.recs.tobytes() == host.recs.tobytes()
+    assert got.shade.tobytes() == host.shade.tobytes()
+    n = (len(host.nodes), len(host.recs))
+    for x in (host, got):
+        x.release()
+    dev.release()
+    return n
+
+
+@pytest.mark.parametrize("name", sorted(tree_scenes()))
+def test_fixture_scenes_give_the_host_tree(name):
+    v, t = tree_scenes()[name].flatten()
+    assert_same_tree(v, t, 10, 7)
+
+
+@pytest.mark.parametrize("depth,prims", [(0, 7), (1, 1), (6, 3), (14, 7), (22, 4), (30, 12)])
+def test_random_soup_limits(depth, prims):
+    v, t = random_soup(5000, 5)
+    assert_same_tree(v, t, depth, prims)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8])
+def test_tiny_inputs(n):
+    v, t = random_soup(max(n, 1), 9)
+    assert_same_tree(v, t[:n], 10, 7)
+
+
+def test_benchmark_scene_tree():
+    sc = scenes.config2()
+    v, t = sc.flatten()
+    nodes, recs = assert_same_tree(v, t, 24, 12)
+    assert nodes > 50_000 and recs > 200_000
+
+
+def test_render_from_an_adopted_device_tree():
+    sc = scenes.sphere_scene(100, 80, 160, 120, reflect=0.5)
+    v, t = sc.flatten()
+    out = []
+    for tree in (FlatTree.build(v, t, 18, 7), DeviceTree.build(v, t, 18, 7)):
+        r = HipRenderer(0)
+        r.load_scene(sc, tree)
+        r.render(RT_HIP_HITIDS)
+        out.append((r.read_frame().copy(), r.read_hit_ids().copy()))
+        r.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_headless_app_with_gpu_build_gives_the_same_frames(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    app = os.path.join(root, "apps", "rt_headless")
+    frames = {}
+    for mode in ("host", "gpu"):
+        d = tmp_path / mode
+        d.mkdir()
+        args = [app, "--size", "256x160", "--squares", "50", "--frames", "2", "--dt", "0.3", "--format", "ppm", "--depth", "16"]
+        subprocess.run(args + (["--gpu-build"] if mode == "gpu" else []), cwd=d, check=True, capture_output=True, timeout=120)
+        frames[mode] = [open(d / "pngs" / f"{i}.ppm", "rb").read() for i in range(2)]
+    assert frames["host"] == frames["gpu"] and frames["host"][0] != frames["host"][1]
