@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from raytracing_amd import dist as rdist
 from raytracing_amd import scenes
-from raytracing_amd.pipe import RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_OVERLAP, FlatTree, HipRenderer
+from raytracing_amd.pipe import RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_OVERLAP, DeviceTree, FlatTree, HipRenderer
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 
@@ -120,6 +120,14 @@ def main():
     tree = FlatTree.build(v, t, args.depth, args.leaf)
     build_s = time.time() - t0
 
+    # the same tree built on the GPU (outside the timed region; reported, and checked against the host tree)
+    DeviceTree.build(v, t, args.depth, args.leaf).release()
+    t0 = time.time()
+    dtree = DeviceTree.build(v, t, args.depth, args.leaf)
+    gpu_build_s = time.time() - t0
+    assert (dtree.n_nodes, dtree.n_recs) == (len(tree.nodes), len(tree.recs))
+    dtree.release()
+
     stream = torch.cuda.current_stream()
     r = HipRenderer(local_rank, stream=stream.cuda_stream)
     r.load_scene(sc, tree)
@@ -208,7 +216,7 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['text']}",
                        "kd_tree": {"max_depth": args.depth, "max_prims_in_leaf": args.leaf, "depth": int(tree.depth),
                                    "nodes": int(len(tree.nodes)), "triangle_refs": int(len(tree.recs)),
-                                   "host_build_s": round(build_s, 3)},
+                                   "host_build_s": round(build_s, 3), "gpu_build_s": round(gpu_build_s, 4)},
                        "schedule": "passes in order on one stream" if args.no_overlap else
                                    "closest-hit/spawn chain on the main stream, shadow + lighting passes on two auxiliary "
                                    "streams (they overlap the chain; per-kernel times include the time a pass shares the chip)",

@@ -92,6 +92,8 @@ void rt_kdtree_device_release( rt_kdtree_device *t );
 /* copy a device tree to host arrays (malloc'ed; rt_kdtree_flat_release frees them) */
 int  rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_flat *out );
 const char *rt_kdtree_device_last_error( void );
+/* the builder keeps its work buffers (per thread and device) for the next build; this frees them */
+void rt_kdtree_device_trim( void );
 
 #ifdef __cplusplus
 }

@@ -488,13 +488,18 @@ void scene_box( const rt_vertex *verts, uint64_t n, rt_box &bbox )
 
 struct Scratch
 {
-	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, flags, scan, cub, info, leafPool, work, sub, order;
+	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, flags, scan, cub, info, leafPool, work, sub, order, totals;
+	uint32_t *hTotals = nullptr;
 	void release()
 	{
-		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &flags, &scan, &cub, &info, &leafPool, &work, &sub, &order } )
+		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &flags, &scan, &cub, &info, &leafPool, &work, &sub, &order, &totals } )
 			v->release();
+		if ( hTotals ) (void) hipHostFree( hTotals );
+		hTotals = nullptr;
 	}
 };
+thread_local Scratch g_scratch;
+thread_local int g_scratchDev = -1;
 
 // carve the per-level node tables out of one allocation
 int level_tab( DVec &buf, size_t n, hipStream_t s, LevelTab &t )
@@ -543,6 +548,20 @@ int exclusive_sum( DVec &cub, const T *in, T *out, size_t n, hipStream_t s )
 
 extern "C" const char *rt_kdtree_device_last_error( void ) { return g_gpu_build_err; }
 
+extern "C" void rt_kdtree_device_trim( void )
+{
+	if ( g_scratchDev >= 0 )
+	{
+		int cur = 0;
+		if ( hipGetDevice( &cur ) == hipSuccess && hipSetDevice( g_scratchDev ) == hipSuccess )
+		{
+			g_scratch.release();
+			(void) hipSetDevice( cur );
+		}
+		g_scratchDev = -1;
+	}
+}
+
 extern "C" void rt_kdtree_device_release( rt_kdtree_device *t )
 {
 	if ( !t )
@@ -574,8 +593,17 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 	scene_box( verts, vertexCount, out->bbox );
 	out->maxMaterial = maxMat;
 
-	Scratch S;
-	struct Guard { Scratch &s; ~Guard() { s.release(); } } guard{ S };
+	// Work buffers are kept between builds of one thread on one device (a frame
+	// loop rebuilds a tree of about the same size every frame; allocating and
+	// freeing them took as long as all the kernels); rt_kdtree_device_trim frees them.
+	int dev = 0;
+	GCHK( hipGetDevice( &dev ) );
+	if ( g_scratchDev != dev )
+	{
+		g_scratch.release();
+		g_scratchDev = dev;
+	}
+	Scratch &S = g_scratch;
 
 	// inputs
 	if ( int rc = S.verts.reserve( sizeof( rt_vertex ) * ( vertexCount ? vertexCount : 1 ), s ) ) return rc;
@@ -603,12 +631,11 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 		GCHK( hipStreamSynchronize( s ) );
 	}
 
-	uint32_t *hTotals = nullptr;
-	GCHK( hipHostMalloc( (void **) &hTotals, 3 * sizeof( uint32_t ), hipHostMallocDefault ) );
-	struct HostGuard { uint32_t *p; ~HostGuard() { (void) hipHostFree( p ); } } hostGuard{ hTotals };
-	DVec totalsDev;
+	if ( !S.hTotals )
+		GCHK( hipHostMalloc( (void **) &S.hTotals, 3 * sizeof( uint32_t ), hipHostMallocDefault ) );
+	uint32_t *hTotals = S.hTotals;
+	DVec &totalsDev = S.totals;
 	if ( int rc = totalsDev.reserve( 16, s ) ) return rc;
-	struct DevGuard { DVec &v; ~DevGuard() { v.release(); } } devGuard{ totalsDev };
 
 	std::vector<uint32_t> levelFirst, levelCount;
 	uint64_t nodesTotal = 0, leafRefs = 0;
