@@ -714,9 +714,17 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 
 	// output buffers (owned by the caller from here on)
 	const uint32_t nRecs = (uint32_t) leafRefs;
-	GCHK( hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * (size_t) nNodes ) );
-	GCHK( hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( (size_t) nRecs + 1 ) ) );
-	GCHK( hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) ) );
+	{
+		hipError_t ea = hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * (size_t) nNodes );
+		if ( ea == hipSuccess ) ea = hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( (size_t) nRecs + 1 ) );
+		if ( ea == hipSuccess ) ea = hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
+		if ( ea != hipSuccess )
+		{
+			snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );
+			rt_kdtree_device_release( out );
+			return 10;
+		}
+	}
 	if ( int rc = S.order.reserve( sizeof( uint32_t ) * ( (size_t) nRecs + 1 ), s ) ) { rt_kdtree_device_release( out ); return rc; }
 	hipLaunchKernelGGL( k_emit, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, info, nNodes, pos, refPos, S.leafPool.as<uint32_t>(),
 		(rt_hip_kdnode *) out->nodes, S.order.as<uint32_t>() );

@@ -1563,7 +1563,8 @@ int rt_hip_set_stream( rt_hip_ctx *c, void *s )
 int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes, const rt_hip_trirec *recs,
 	uint64_t nRecs, const rt_hip_trishade *shade, uint64_t nTris, const rt_box *bbox, int depth )
 {
-	if ( !c || !nodes || !bbox || nNodes == 0 ) return fail( "rt_hip_upload_tree: bad arguments" );
+	if ( !c || !nodes || !bbox || nNodes == 0 || ( nRecs && !recs ) || ( nTris && !shade ) )
+		return fail( "rt_hip_upload_tree: bad arguments" );
 	if ( depth > RT_HIP_MAX_TREE_DEPTH )
 		return fail( "rt_hip_upload_tree: tree depth %d exceeds the traversal stack (%d)", depth, RT_HIP_MAX_TREE_DEPTH );
 	if ( nNodes >= ( 1ull << 30 ) || nRecs >= ( 1ull << 30 ) || nTris >= ( 1ull << 31 ) )
@@ -1571,6 +1572,9 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 	// host-side shape check: every link and record range must stay inside the
 	// arrays (an out-of-range link would fault the GPU), and children must
 	// come after their parent so no traversal can loop
+	// The traversal stack is sized by the depth, so the depth is measured here
+	// and not taken from the caller: level[i] = longest path from the root.
+	std::vector<uint8_t> level( nNodes, 0 );
 	for ( uint64_t i = 0; i < nNodes; ++i )
 	{
 		uint32_t b = nodes[i].b;
@@ -1578,9 +1582,16 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 		{
 			if ( (uint64_t) nodes[i].a + ( b >> 2 ) > nRecs )
 				return fail( "rt_hip_upload_tree: leaf %llu references records beyond %llu", (unsigned long long) i, (unsigned long long) nRecs );
+			continue;
 		}
-		else if ( ( b >> 2 ) >= nNodes || ( b >> 2 ) <= i || i + 1 >= nNodes )
+		const uint64_t right = b >> 2;
+		if ( right >= nNodes || right <= i || i + 1 >= nNodes )
 			return fail( "rt_hip_upload_tree: node %llu has an invalid child link", (unsigned long long) i );
+		if ( level[i] >= RT_HIP_MAX_TREE_DEPTH )
+			return fail( "rt_hip_upload_tree: the tree is deeper than the traversal stack (%d)", RT_HIP_MAX_TREE_DEPTH );
+		const uint8_t l = (uint8_t) ( level[i] + 1 );
+		if ( level[i + 1] < l ) level[i + 1] = l;
+		if ( level[right] < l ) level[right] = l;
 	}
 	uint64_t maxMat = 0;
 	for ( uint64_t i = 0; i < nRecs; ++i )

@@ -220,6 +220,44 @@ def test_errors_are_reported_not_swallowed():
         HipRenderer(99)
 
 
+def test_malformed_trees_are_rejected_on_the_host():
+    """A link or record range outside the arrays, or a tree deeper than the
+    traversal stack (whatever depth the caller declares), must never reach
+    the GPU."""
+    import types
+    from raytracing_amd._lib import RtError
+    from raytracing_amd.pipe import kdnode
+    sc = edge_scene("few_tris")
+    v, t = sc.flatten()
+    good = FlatTree.build(v, t)
+    r = HipRenderer(0)
+
+    def variant(nodes, depth=None):
+        return types.SimpleNamespace(nodes=np.ascontiguousarray(nodes, kdnode), recs=good.recs, shade=good.shade,
+                                     bbox=good.bbox, depth=good.depth if depth is None else depth)
+
+    r.upload_tree(variant(good.nodes.copy()))                      # the unmodified copy is accepted
+    leaf = int(np.flatnonzero((good.nodes["b"] & 3) == 3)[0])
+    bad = good.nodes.copy()
+    bad["b"][leaf] = ((len(good.recs) + 1) << 2) | 3               # leaf range beyond the records
+    with pytest.raises(RtError):
+        r.upload_tree(variant(bad))
+    inner = np.zeros(3, kdnode)
+    inner["b"][0] = (7 << 2) | 0                                   # right child beyond the array
+    inner["b"][1:] = 3
+    with pytest.raises(RtError):
+        r.upload_tree(variant(inner))
+    # a chain of 70 inner nodes, declared as depth 10
+    n = 70
+    chain = np.zeros(2 * n + 1, kdnode)
+    for i in range(n):
+        chain["b"][i] = ((2 * n - i) << 2) | 0                     # left = i + 1, right = a leaf at the end
+    chain["b"][n:] = 3                                             # empty leaves
+    with pytest.raises(RtError, match="deeper"):
+        r.upload_tree(variant(chain, depth=10))
+    r.close()
+
+
 def test_config2_full_size_sampled_against_oracle():
     """100k triangles at 1920x1080 on the deep tree: every 12th pixel of every
     12th row against the oracle, plus image-wide invariants."""
