@@ -134,7 +134,7 @@ def main():
     r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
     r.set_tile(rdist.BAND_H, world, rank)
     rows = r.local_rows
-    pad = rdist.max_local_rows(sc.h, rdist.BAND_H, world)
+    pad = rdist.padded_rows(sc.h, rdist.BAND_H, world)
     frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
 
     def step(flags=0):

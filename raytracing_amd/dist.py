@@ -33,6 +33,13 @@ def max_local_rows(h, band_h, n_parts):
     return max(local_rows(h, band_h, n_parts, p) for p in range(n_parts))
 
 
+def padded_rows(h, band_h, n_parts):
+    """Rows of the per-rank buffer the gather exchanges: the largest share,
+    rounded up to whole bands (every rank sends the same amount)."""
+    n_bands = (h + band_h - 1) // band_h
+    return ((n_bands + n_parts - 1) // n_parts) * band_h
+
+
 def assemble(parts, h, w, band_h):
     """parts[r]: [>= local_rows(r), w, 4] tensor of rank r -> [h, w, 4]."""
     n = len(parts)
@@ -43,26 +50,43 @@ def assemble(parts, h, w, band_h):
     return out
 
 
+_recv = {}      # receive buffer of the destination rank, kept between frames
+
+
 def gather_frame(local, h, w, band_h=BAND_H, dst=0, group=None):
-    """All ranks pass their [rows, w, 4] uint8 tensor (rows may differ by one
-    band between ranks; it is padded to the common maximum).  Rank `dst`
-    returns the assembled [h, w, 4] frame, the others None."""
+    """All ranks pass their [rows, w, 4] uint8 tensor (any row count from
+    their own share up; padded_rows() avoids a copy).  Rank `dst` returns the
+    assembled [h, w, 4] frame, the others None.
+
+    Band b lives on rank b mod N as local band b div N, so with every share
+    padded to B whole bands the received [N, B, band_h, w, 4] block becomes
+    the frame by swapping its first two axes: one strided copy, no index
+    arrays, nothing allocated per frame (the receive buffer is reused, so the
+    returned frame is valid until the next call with the same geometry)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return local[:h]
-    pad = max_local_rows(h, band_h, world)
+    pad = padded_rows(h, band_h, world)
     if local.shape[0] < pad:
         local = torch.cat([local, local.new_zeros((pad - local.shape[0], w, 4))])
     elif local.shape[0] > pad:
         local = local[:pad]
     local = local.contiguous()
     # all-to-one: every source uses its own direct link to dst
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    bufs = None
+    if rank == dst:
+        key = (world, pad, w, local.dtype, local.device)
+        if key not in _recv:
+            _recv.clear()
+            _recv[key] = torch.empty((world, pad, w, 4), dtype=local.dtype, device=local.device)
+        big = _recv[key]
+        bufs = [big[i] for i in range(world)]
     dist.gather(local, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return assemble(bufs, h, w, band_h)
+    nb = pad // band_h
+    return big.view(world, nb, band_h, w, 4).permute(1, 0, 2, 3, 4).reshape(nb * world * band_h, w, 4)[:h]
 
 
 def sequence_frames(n_frames, n_parts, part, start=0):

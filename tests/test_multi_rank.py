@@ -18,6 +18,7 @@ def test_band_rows_partition_the_image(h, band, parts):
     allr = np.concatenate(rows)
     assert sorted(allr.tolist()) == list(range(h))
     assert max(len(r) for r in rows) == rdist.max_local_rows(h, band, parts)
+    assert 0 <= rdist.padded_rows(h, band, parts) - rdist.max_local_rows(h, band, parts) < band
     for r in rows:            # local order is increasing, bands stay contiguous
         assert (np.diff(r) > 0).all()
 
@@ -39,20 +40,28 @@ def _worker(rank, world, port, h, w, band, q):
     local[:, :, 0] = torch.as_tensor(rows % 251, dtype=torch.uint8)[:, None]
     local[:, :, 1] = rank
     local[:, :, 2] = torch.arange(w, dtype=torch.int64).remainder(256).to(torch.uint8)[None, :]
-    frame = rdist.gather_frame(local, h, w, band)
+    ok = True
+    for call in range(2):         # the second call reuses the receive buffer; its input is already padded
+        if call == 1:
+            local = torch.cat([local, local.new_zeros((rdist.padded_rows(h, band, world) - len(rows), w, 4))])
+            local[:len(rows), :, 3] = 7
+        frame = rdist.gather_frame(local, h, w, band)
+        if rank == 0:
+            ok = ok and frame.shape == (h, w, 4)
+            ok = ok and bool((frame[:, :, 0].to(torch.int64) == (torch.arange(h) % 251)[:, None]).all())
+            owner = torch.as_tensor((np.arange(h) // band) % world)
+            ok = ok and bool((frame[:, :, 1].to(torch.int64) == owner[:, None]).all())
+            ok = ok and bool((frame[:, :, 2].to(torch.int64) == (torch.arange(w) % 256)[None, :]).all())
+            ok = ok and bool((frame[:, :, 3] == 7 * call).all())
+        else:
+            assert frame is None
     if rank == 0:
-        ok = bool((frame[:, :, 0].to(torch.int64) == (torch.arange(h) % 251)[:, None]).all())
-        owner = torch.as_tensor((np.arange(h) // band) % world)
-        ok = ok and bool((frame[:, :, 1].to(torch.int64) == owner[:, None]).all())
-        ok = ok and bool((frame[:, :, 2].to(torch.int64) == (torch.arange(w) % 256)[None, :]).all())
         q.put(ok)
-    else:
-        assert frame is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w,band", [(70, 40, 16), (64, 33, 16), (9, 5, 4)])
+@pytest.mark.parametrize("h,w,band", [(70, 40, 16), (64, 33, 16), (9, 5, 4), (3, 4, 16), (40, 8, 16)])
 def test_gather_frame_two_ranks_gloo(h, w, band):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
