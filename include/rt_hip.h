@@ -146,6 +146,12 @@ int  rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags );
 int  rt_hip_sync( rt_hip_ctx *c );
 int  rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host );        /* internal frame buffer -> host, synchronous */
 int  rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host );      /* after RT_HIP_HITIDS */
+/* Page-locked host memory for the frames that are read back (the reference's
+ * blocking clEnqueueReadBuffer went into malloc'ed screenData,
+ * rt_funcs_render_pipe.c:567-569): read-backs into it run at link speed
+ * instead of through a staging copy.  NULL when the driver refuses. */
+void *rt_hip_alloc_host( rt_hip_ctx *c, size_t bytes );
+void rt_hip_free_host( rt_hip_ctx *c, void *host );
 int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
 /* Per-frame kernel time in ms, averaged over the frames rendered with
  * RT_HIP_TIMING since the previous call (at most the last 32): ms[0] =

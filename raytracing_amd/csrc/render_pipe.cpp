@@ -32,6 +32,7 @@ struct rt_pipe_impl
 	int bandH = 16, nParts = 1, part = 0;
 	bool matsDirty = true;
 	bool haveTree = false;
+	bool screenPinned = false;
 	uint64_t geomHash = 0, geomBytes = 0;
 	rt_kdtree_flat lastInfo;          // counts of the tree on the device (arrays released)
 };
@@ -134,13 +135,28 @@ void rt_render_pipe_create( rt_render_pipe *pRp, int w, int h )
 	rt_render_pipe_set_image_size( pRp, w, h );
 }
 
+static void release_screen( rt_render_pipe *pRp, rt_pipe_impl *im )
+{
+	if ( im->screenPinned )
+		rt_hip_free_host( im->hip, pRp->screenData );
+	else
+		free( pRp->screenData );
+	im->screenPinned = false;
+	pRp->screenData = NULL;
+}
+
 void rt_render_pipe_set_image_size( rt_render_pipe *pRp, int w, int h )
 {
 	rt_pipe_impl *im = impl_of( pRp );
 	if ( rt_hip_set_image( im->hip, w, h ) )
 		die_hip( "rt_render_pipe_set_image_size" );
-	free( pRp->screenData );
-	pRp->screenData = (rt_argb *) malloc( sizeof( rt_argb ) * (size_t) w * (size_t) h );
+	release_screen( pRp, im );
+	const size_t bytes = sizeof( rt_argb ) * (size_t) w * (size_t) h;
+	// page-locked where the driver allows it: the read-back then needs no staging copy
+	pRp->screenData = (rt_argb *) rt_hip_alloc_host( im->hip, bytes );
+	im->screenPinned = pRp->screenData != NULL;
+	if ( !pRp->screenData )
+		pRp->screenData = (rt_argb *) malloc( bytes );
 	pRp->w = w;
 	pRp->h = h;
 }
@@ -337,9 +353,13 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 {
 	rt_pipe_impl *im = impl_of( pRp );
 
+	// the change detector is only paid for when a tree may be reused
 	uint64_t h = 1469598103934665603ull;
-	h = hash_bytes( im->verts.data(), im->verts.size() * sizeof( rt_vertex ), h );
-	h = hash_bytes( im->tris.data(), im->tris.size() * sizeof( rt_triangle ), h );
+	if ( im->treeCache )
+	{
+		h = hash_bytes( im->verts.data(), im->verts.size() * sizeof( rt_vertex ), h );
+		h = hash_bytes( im->tris.data(), im->tris.size() * sizeof( rt_triangle ), h );
+	}
 	const uint64_t bytes = im->verts.size() * sizeof( rt_vertex ) + im->tris.size() * sizeof( rt_triangle );
 	const bool reuse = im->treeCache && im->haveTree && h == im->geomHash && bytes == im->geomBytes;
 	if ( !reuse && im->gpuBuild )
@@ -420,7 +440,10 @@ void rt_render_pipe_cleanup( rt_render_pipe *pRp )
 {
 	if ( !pRp )
 		exit( -1 );
-	free( pRp->screenData );
+	if ( pRp->impl )
+		release_screen( pRp, pRp->impl );
+	else
+		free( pRp->screenData );
 	pRp->screenData = NULL;
 	if ( pRp->impl )
 	{

@@ -1961,6 +1961,28 @@ int rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host )
 	return 0;
 }
 
+void *rt_hip_alloc_host( rt_hip_ctx *c, size_t bytes )
+{
+	void *p = nullptr;
+	if ( !c || !bytes || hipSetDevice( c->device ) != hipSuccess || hipHostMalloc( &p, bytes, hipHostMallocDefault ) != hipSuccess )
+	{
+		// the caller falls back to pageable memory: do not leave the failure behind
+		// as the runtime's last error, where the next launch check would find it
+		(void) hipGetLastError();
+		fail( "rt_hip_alloc_host: %zu bytes of page-locked memory not available", bytes );
+		return nullptr;
+	}
+	return p;
+}
+
+void rt_hip_free_host( rt_hip_ctx *c, void *host )
+{
+	if ( !c || !host )
+		return;
+	(void) hipSetDevice( c->device );
+	(void) hipHostFree( host );
+}
+
 int rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host )
 {
 	if ( !c || !host ) return fail( "rt_hip_read_hit_ids: bad arguments" );
