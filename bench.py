@@ -218,7 +218,7 @@ def main():
                                    "nodes": int(len(tree.nodes)), "triangle_refs": int(len(tree.recs)),
                                    "host_build_s": round(build_s, 3), "gpu_build_s": round(gpu_build_s, 4)},
                        "schedule": "passes in order on one stream" if args.no_overlap else
-                                   "closest-hit/spawn chain on the main stream, shadow + lighting passes on two auxiliary "
+                                   "closest-hit chain on the main stream, shadow + lighting passes on two auxiliary "
                                    "streams (they overlap the chain; per-kernel times include the time a pass shares the chip)",
                        "rays_per_frame": int(rays_frame), "closest_rays": int(cnt[0]), "shadow_rays": int(cnt[1]),
                        "parallelism": "single GPU" if world == 1 else

@@ -4,22 +4,22 @@
 // work lists in HBM instead of one per-pixel megakernel:
 //
 //   for slot k = 0 .. STACK_SIZE-1            (slot = index in the pixel's ray list)
-//     k_closest<k>  ray list k  -> closest hit (spheres brute force + kd tree)
+//     k_closest<k>  ray list k  -> closest hit (spheres brute force + kd tree);
 //                   misses finish their slot, hits are COMPACTED into a hit list
+//                   and shaded as far as the next slot needs it: hit point,
+//                   normal, child rays appended (wave-aggregated atomics) to the
+//                   ray lists of the slots they occupy
 //     k_shadow<k>   hit list k x lights -> one shadow traversal per item (lean
 //                   register state: only what the traversal needs)
-//     k_spawn<k>    hit list k  -> hit point, normal; child rays are appended
-//                   (wave-aggregated atomics) to the ray lists of the slots they
-//                   occupy; no traversal, pure streaming
 //     k_light<k>    hit list k + shadow sums -> Phong terms, slot colour
 //   k_fold          per pixel: fold child colours into parents back to front,
 //                   clamp, truncate to 8-bit BGRA
 //
-// Only closest -> spawn -> closest of the next slot is a dependency chain; the
-// shadow and lighting passes of a slot hang off it.  The deep slots hold few
-// but very long rays (a few busy waves, the rest of the chip idle), so the
-// chain runs on the caller's stream and the shadow / lighting passes on two
-// auxiliary streams that fill the idle part of the chip.
+// k_closest<k> -> k_closest<k+1> is the only dependency chain; the shadow and
+// lighting passes of a slot hang off it.  The deep slots hold few but very
+// long rays (a few busy waves, the rest of the chip idle), so the chain runs
+// on the caller's stream and the shadow / lighting passes on two auxiliary
+// streams that fill the idle part of the chip.
 //
 // This is the reference's iterative ray tree (CL/rt_funcs_primitives.cl:584-728)
 // turned inside out: the reference walks the <= 6 slots of ONE pixel in a
@@ -51,8 +51,11 @@
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK  12     // traversal stack entries per lane kept in LDS
 #endif
-#ifndef RT_WAVES
-#define RT_WAVES      6      // resident waves per SIMD the traversal kernels are compiled for
+#ifndef RT_WAVES_CLOSEST
+#define RT_WAVES_CLOSEST 4   // resident waves per SIMD the closest-hit kernel is compiled for (128 VGPRs)
+#endif
+#ifndef RT_WAVES_SHADOW
+#define RT_WAVES_SHADOW  6   // the same for the shadow kernel (80 VGPRs)
 #endif
 #define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
@@ -106,7 +109,6 @@ struct Counters
 	Ctr rayCount[RT_MAX_SLOTS];           // entries in ray list k (k >= 1)
 	Ctr headClosest[RT_MAX_SLOTS];        // chunk dispenser of k_closest
 	Ctr hitCount[RT_MAX_SLOTS];           // entries in the hit list of slot k
-	Ctr headSpawn[RT_MAX_SLOTS];          // chunk dispenser of k_spawn
 	Ctr headShade[RT_MAX_SLOTS];          // chunk dispenser of k_light
 	Ctr headShadow[RT_MAX_SLOTS];         // chunk dispenser of k_shadow
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
@@ -123,7 +125,7 @@ struct Work
 	// slots overlap in time
 	float4 *hitA;                         // (entry, t, u, v)
 	uint2  *hitB;                         // (id | sphere flag, b)
-	float4 *hitN;                         // (shading normal xyz, material slot), written by k_spawn
+	float4 *hitN;                         // (shading normal xyz, material slot), written by k_closest
 	float4 *res;                          // [slot * npix + pix] (col rgb, parent slot)
 	float4 *fac;                          // [slot * npix + pix] weight of this slot in its parent
 	float  *shadow;                       // [(slot * nLights + light) * npix + hit] summed shadow opacity
@@ -896,11 +898,35 @@ DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_
 	return c < chunks;
 }
 
+DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
+{
+	// lanes of one wave may target different slots: aggregate per slot
+#pragma unroll
+	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
+	{
+		bool mine = want && target == s;
+		if ( __ballot( mine ) == 0ull )
+			continue;
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
+		uint32_t idx = list_append( &W.ctr->rayCount[s].v, rv[s], mine, block,
+			[&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
+		if ( mine )
+		{
+			size_t o = lbase + idx;
+			W.rayA[o] = make_float4( r.src.x, r.src.y, r.src.z, __uint_as_float( pix ) );
+			W.rayB[o] = make_float4( r.dest.x, r.dest.y, r.dest.z,
+				__uint_as_float( (uint32_t) parent | ( (uint32_t) type << 8 ) ) );
+			W.rayC[o] = make_float4( coef.x, coef.y, coef.z, 0.0f );
+			W.rayD[o] = make_float4( P.x, P.y, P.z, 0.0f );
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------
 // k_closest: closest-hit pass of one slot
 // ---------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, Work W, int slot, int wantIds )
+__global__ __launch_bounds__( RT_BLOCK, RT_WAVES_CLOSEST ) void k_closest( DevScene S, Work W, int slot, int wantIds )
 {
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
@@ -909,6 +935,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 	uint32_t first;
 	Grab grab = { 0u };
 	Resv resv = { 0u, 0u };
+	Resv rv[RT_MAX_SLOTS] = {};
 	const uint32_t block = resv_block( count );
 	const size_t hbase = (size_t) slot * W.cap;
 	auto holeHit = [&]( uint32_t i ) { W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); };
@@ -955,13 +982,85 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 		const bool hit = triHit || sphHit;
 
 		const uint32_t hidx = list_append( &W.ctr->hitCount[slot].v, resv, hit, block, holeHit );
+		bool pushRefl = false, pushRefr = false;
+		Ray rRefl, rRefr;
+		f3 P = F3( 0.0f, 0.0f, 0.0f ), cRefl = P, cRefr = P;
+		int sp = 0;
 		if ( hit )
 		{
 			const size_t ho = hbase + hidx;
-			W.hitA[ho] = make_float4( __uint_as_float( e ), triHit ? h.minT : prMinT, h.minU, h.minV );
-			W.hitB[ho] = make_uint2( triHit ? h.prN : ( prN | 0x80000000u ), (uint32_t) ( triHit ? h.nearestB : prB ) );
+			const float tHit = triHit ? h.minT : prMinT;
+			const uint32_t id = triHit ? h.prN : ( prN | 0x80000000u );
+			const int bNearest = triHit ? h.nearestB : prB;
+			W.hitA[ho] = make_float4( __uint_as_float( e ), tHit, h.minU, h.minV );
+			W.hitB[ho] = make_uint2( id, (uint32_t) bNearest );
+
+			// shading normal and child rays of the hit (the next slot's closest-hit pass
+			// waits for nothing else)
+			f3 N;
+			uint32_t matIdx;
+			// hit point: dest * t + src for triangles (:66) and spheres (:42-43) alike
+			P = add3( mul3( rh.ray.dest, tHit ), rh.ray.src );
+			if ( id & 0x80000000u )
+			{
+				// sphere normal, CL/rt_funcs_primitives.cl:45-46
+				const uint32_t si = id & 0x7fffffffu;
+				const float4 sph = S.spheres[si];
+				matIdx = S.sphereMat[si];
+				N = div3( sub3( P, F3( sph.x, sph.y, sph.z ) ), sph.w );
+				N = mul3( N, (float) bNearest );
+			}
+			else
+			{
+				// barycentric normal (not normalised), :68-71
+				const float4 *sp4 = S.shade + 3u * (size_t) id;
+				const float4 a = sp4[0], b = sp4[1], c = sp4[2];
+				const f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
+				const float u = h.minU, v = h.minV;
+				matIdx = __float_as_uint( c.y );
+				N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
+			}
+			W.hitN[ho] = make_float4( N.x, N.y, N.z, __uint_as_float( matIdx ) );
+
+			const rt_material &mat = S.mats[matIdx];
+			const f3 refl = rgb_of( mat.reflect );
+			const float alpha = mat.color.a;
+
+			sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
+
+			// reflection ray :643-655
+			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 ) && ( ( refl.x + refl.y + refl.z ) > 0.0f ) )
+			{
+				++sp;
+				pushRefl = true;
+				rRefl.dest = reflect3( rh.ray.dest, N );
+				rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
+				cRefl = refl;
+			}
+			// refraction ray :657-677
+			if ( ( ( sp + 1 ) < S.stackSize ) && ( alpha < 0.99f ) )
+			{
+				const float nRel = ENV_OPT_DENSITY / mat.optDens;
+				const float cosI = dot3( N, rh.ray.dest );
+				const float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
+				if ( sinT < 1.0f )
+				{
+					++sp;
+					pushRefr = true;
+					rRefr.dest = norm3( sub3( mul3( rh.ray.dest, nRel ),
+						mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
+					rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
+					const float lf = mat.lightFalloff;
+					cRefr = F3( mat.color.r * lf, mat.color.g * lf, mat.color.b * lf );
+				}
+			}
+			if ( slot == 0 || pushRefl || pushRefr )
+				W.stackPos[rh.pix] = (uint32_t) sp;
 		}
-		else if ( valid )
+		// slot numbers: reflection takes the first new slot, refraction the next
+		push_ray( W, rv, block, sp - ( pushRefr ? 1 : 0 ), pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
+		push_ray( W, rv, block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
+		if ( !hit && valid )
 		{
 			const size_t o = (size_t) slot * W.npix + rh.pix;
 			W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( parent_of( rh.pk ) ) );
@@ -977,6 +1076,12 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_closest( DevScene S, W
 			W.hitId[rh.pix] = triHit ? (int32_t) h.prN : ( sphHit ? -2 - (int32_t) prN : -1 );
 	}
 	list_close( resv, holeHit );
+#pragma unroll
+	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
+	{
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
+		list_close( rv[s], [&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
+	}
 	if ( STATS )
 		flush_tally( W, tl, false );
 }
@@ -999,7 +1104,7 @@ DEVI void to_light( const DevScene &S, int o, f3 P, f3 &toLight, float &d )
 // carries the sphere sum keeps it when the ray misses the scene box, so the
 // sphere opacity is then counted twice, as in the reference.
 template <bool STATS>
-__global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Work W, int slot )
+__global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScene S, Work W, int slot )
 {
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
@@ -1066,7 +1171,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES ) void k_shadow( DevScene S, Wo
 }
 
 // ---------------------------------------------------------------------------
-// shading of the compacted hits of one slot: child rays (k_spawn), lighting (k_light)
+// lighting of the compacted hits of one slot (k_light)
 // ---------------------------------------------------------------------------
 
 // CL/rt_funcs_primitives.cl:450-564 with the shadow term taken from k_shadow
@@ -1109,144 +1214,8 @@ DEVI f3 light_point( const DevScene &S, const Work &W, int slot, uint32_t h, f3 
 	return col;
 }
 
-DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
-{
-	// lanes of one wave may target different slots: aggregate per slot
-#pragma unroll
-	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
-	{
-		bool mine = want && target == s;
-		if ( __ballot( mine ) == 0ull )
-			continue;
-		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
-		uint32_t idx = list_append( &W.ctr->rayCount[s].v, rv[s], mine, block,
-			[&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
-		if ( mine )
-		{
-			size_t o = lbase + idx;
-			W.rayA[o] = make_float4( r.src.x, r.src.y, r.src.z, __uint_as_float( pix ) );
-			W.rayB[o] = make_float4( r.dest.x, r.dest.y, r.dest.z,
-				__uint_as_float( (uint32_t) parent | ( (uint32_t) type << 8 ) ) );
-			W.rayC[o] = make_float4( coef.x, coef.y, coef.z, 0.0f );
-			W.rayD[o] = make_float4( P.x, P.y, P.z, 0.0f );
-		}
-	}
-}
-
-// k_spawn: for every hit of one slot the shading normal and the child rays.
-// This is the part of the shading the next slot's traversal waits for; the
-// lighting (k_light) needs the shadow sums and runs beside later traversals.
-__global__ __launch_bounds__( RT_BLOCK ) void k_spawn( DevScene S, Work W, int slot )
-{
-	const uint32_t count = W.ctr->hitCount[slot].v;
-	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
-	const size_t base = (size_t) slot * W.cap;
-	uint32_t first;
-	Grab grab = { 0u };
-	Resv rv[RT_MAX_SLOTS] = {};
-	const uint32_t block = resv_block( count );
-	while ( next_chunk( &W.ctr->headSpawn[slot].v, count, grab, first, RT_STREAM_DYN ) )
-	{
-		const uint32_t h = first + lane_id();
-		bool valid = h < count;
-
-		RayHead rh;
-		rh.pix = rh.pk = 0u;
-		float4 ha = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-		uint2 hb = make_uint2( 0u, 0u );
-		if ( valid )
-		{
-			ha = W.hitA[base + h];
-			hb = W.hitB[base + h];
-			valid = __float_as_uint( ha.x ) != RT_INVALID && load_ray( S, W, slot, __float_as_uint( ha.x ), rayCount, rh );
-		}
-
-		bool pushRefl = false, pushRefr = false;
-		Ray rRefl, rRefr;
-		f3 P = F3( 0.0f, 0.0f, 0.0f ), cRefl = P, cRefr = P;
-		int sp = 0;
-
-		if ( valid )
-		{
-			f3 N;
-			uint32_t matIdx;
-			const int bNearest = (int) hb.y;
-			const float t = ha.y;
-
-			// hit point: dest * t + src for triangles (:66) and spheres (:42-43) alike
-			P = add3( mul3( rh.ray.dest, t ), rh.ray.src );
-			if ( hb.x & 0x80000000u )
-			{
-				// sphere normal, CL/rt_funcs_primitives.cl:45-46
-				const uint32_t si = hb.x & 0x7fffffffu;
-				const float4 s = S.spheres[si];
-				matIdx = S.sphereMat[si];
-				N = div3( sub3( P, F3( s.x, s.y, s.z ) ), s.w );
-				N = mul3( N, (float) bNearest );
-			}
-			else
-			{
-				// barycentric normal (not normalised), :68-71
-				const float4 *sp4 = S.shade + 3u * (size_t) hb.x;
-				const float4 a = sp4[0], b = sp4[1], c = sp4[2];
-				const f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
-				const float u = ha.z, v = ha.w;
-				matIdx = __float_as_uint( c.y );
-				N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
-			}
-			W.hitN[base + h] = make_float4( N.x, N.y, N.z, __uint_as_float( matIdx ) );
-
-			const rt_material &mat = S.mats[matIdx];
-			const f3 refl = rgb_of( mat.reflect );
-			const float alpha = mat.color.a;
-
-			sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
-
-			// reflection ray :643-655
-			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 ) && ( ( refl.x + refl.y + refl.z ) > 0.0f ) )
-			{
-				++sp;
-				pushRefl = true;
-				rRefl.dest = reflect3( rh.ray.dest, N );
-				rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
-				cRefl = refl;
-			}
-			// refraction ray :657-677
-			if ( ( ( sp + 1 ) < S.stackSize ) && ( alpha < 0.99f ) )
-			{
-				const float nRel = ENV_OPT_DENSITY / mat.optDens;
-				const float cosI = dot3( N, rh.ray.dest );
-				const float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
-				if ( sinT < 1.0f )
-				{
-					++sp;
-					pushRefr = true;
-					rRefr.dest = norm3( sub3( mul3( rh.ray.dest, nRel ),
-						mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
-					rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
-					const float lf = mat.lightFalloff;
-					cRefr = F3( mat.color.r * lf, mat.color.g * lf, mat.color.b * lf );
-				}
-			}
-			if ( slot == 0 || pushRefl || pushRefr )
-				W.stackPos[rh.pix] = (uint32_t) sp;
-		}
-
-		// slot numbers: reflection takes the first new slot, refraction the next
-		const int reflSlot = sp - ( pushRefr ? 1 : 0 );
-		push_ray( W, rv, block, reflSlot, pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
-		push_ray( W, rv, block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
-	}
-#pragma unroll
-	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
-	{
-		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
-		list_close( rv[s], [&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
-	}
-}
-
 // k_light: colour of every hit of one slot (needs k_shadow's sums and
-// k_spawn's normals) and the weight of the slot in its parent
+// k_closest's normals) and the weight of the slot in its parent
 __global__ __launch_bounds__( RT_BLOCK ) void k_light( DevScene S, Work W, int slot )
 {
 	const uint32_t count = W.ctr->hitCount[slot].v;
@@ -1399,16 +1368,16 @@ struct rt_hip_ctx
 	int treeDepth = 0;
 	int allocStack = 0;           // stack size the work buffers were sized for
 	bool workDirty = true;
-	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridSpawn = 0, gridLight = 0;
+	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridLight = 0;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[2] = { nullptr, nullptr };   // shadow + lighting passes (even / odd slots)
-	hipEvent_t evHit[RT_MAX_SLOTS] = {}, evSpawn[RT_MAX_SLOTS] = {}, evLit[RT_MAX_SLOTS] = {};
+	hipEvent_t evHit[RT_MAX_SLOTS] = {}, evLit[RT_MAX_SLOTS] = {};
 	int overlap = 1;
 	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
 	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
-	// [frame][(slot * 4 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop
-	hipEvent_t ev[RT_TIMED_FRAMES][8 * RT_MAX_SLOTS + 4] = {};
+	// [frame][(slot * 3 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop
+	hipEvent_t ev[RT_TIMED_FRAMES][6 * RT_MAX_SLOTS + 4] = {};
 	bool haveEvents = false;
 	int timedSlots = 0, timedFrames = 0;
 	uint32_t validPixels = 0;
@@ -1491,10 +1460,10 @@ rt_hip_ctx *rt_hip_create( int device )
 
 	// persistent grids: one resident wave set per CU, as many blocks as fit
 	int occ = 0;
-	struct { const void *f; int *dst; int *occ; } ks[6] = {
+	struct { const void *f; int *dst; int *occ; } ks[5] = {
 		{ (const void *) k_closest<false>, &c->gridClosest[0], nullptr }, { (const void *) k_closest<true>, &c->gridClosest[1], nullptr },
 		{ (const void *) k_shadow<false>, &c->gridShadow[0], &c->occShadow[0] }, { (const void *) k_shadow<true>, &c->gridShadow[1], &c->occShadow[1] },
-		{ (const void *) k_spawn, &c->gridSpawn, nullptr }, { (const void *) k_light, &c->gridLight, nullptr } };
+		{ (const void *) k_light, &c->gridLight, nullptr } };
 	for ( auto &k : ks )
 	{
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
@@ -1507,8 +1476,7 @@ rt_hip_ctx *rt_hip_create( int device )
 		if ( k.occ ) *k.occ = occ;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
 	}
-	// the streaming passes gain nothing from more than a few waves per SIMD
-	if ( c->gridSpawn > RT_STREAM_OCC * c->numCU ) c->gridSpawn = RT_STREAM_OCC * c->numCU;
+	// a streaming pass gains nothing from more than a few waves per SIMD
 	if ( c->gridLight > RT_STREAM_OCC * c->numCU ) c->gridLight = RT_STREAM_OCC * c->numCU;
 
 	int prLow = 0, prHigh = 0;
@@ -1517,7 +1485,6 @@ rt_hip_ctx *rt_hip_create( int device )
 		ok = ok && hipStreamCreateWithPriority( &a, hipStreamNonBlocking, prLow ) == hipSuccess;
 	for ( int k = 0; k < RT_MAX_SLOTS && ok; ++k )
 		ok = hipEventCreateWithFlags( &c->evHit[k], hipEventDisableTiming ) == hipSuccess
-			&& hipEventCreateWithFlags( &c->evSpawn[k], hipEventDisableTiming ) == hipSuccess
 			&& hipEventCreateWithFlags( &c->evLit[k], hipEventDisableTiming ) == hipSuccess;
 	if ( !ok )
 	{
@@ -1538,7 +1505,6 @@ void rt_hip_destroy( rt_hip_ctx *c )
 	for ( int k = 0; k < RT_MAX_SLOTS; ++k )
 	{
 		if ( c->evHit[k] ) (void) hipEventDestroy( c->evHit[k] );
-		if ( c->evSpawn[k] ) (void) hipEventDestroy( c->evSpawn[k] );
 		if ( c->evLit[k] ) (void) hipEventDestroy( c->evLit[k] );
 	}
 	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights,
@@ -1876,7 +1842,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		c->timedFrames = 0;
 	}
 	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
-	hipEvent_t *evFold = ev + 8 * RT_MAX_SLOTS, *evFrame = evFold + 2;
+	hipEvent_t *evFold = ev + 6 * RT_MAX_SLOTS, *evFrame = evFold + 2;
 	const bool overlap = c->overlap && S.stackSize > 1;
 	const int lights = S.nLights > 0 ? S.nLights : 1;
 
@@ -1886,7 +1852,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		return 0;
 	for ( int k = 0; k < S.stackSize; ++k )
 	{
-		hipEvent_t *e = ev + 8 * k;
+		hipEvent_t *e = ev + 6 * k;
 		hipStream_t x = overlap ? c->aux[k & 1] : s;
 		// every traversal running at the same time needs its own stack-overflow strip
 		Work Wx = W;
@@ -1894,12 +1860,11 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 
 		// a persistent grid never needs more waves than there are chunks
 		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
-		int gc = c->gridClosest[stats], gp = c->gridSpawn, gl = c->gridLight;
+		int gc = c->gridClosest[stats], gl = c->gridLight;
 		// beside the chain a shadow pass leaves part of every CU to it
 		int gw = overlap && c->occShadow[stats] > RT_AUX_OCC ? RT_AUX_OCC * c->numCU : c->gridShadow[stats];
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
 		if ( k == 0 && want * (uint32_t) lights < (uint32_t) gw ) gw = (int) ( want ? want * lights : 1u );
-		if ( k == 0 && want < (uint32_t) gp ) gp = (int) ( want ? want : 1u );
 		if ( k == 0 && want < (uint32_t) gl ) gl = (int) ( want ? want : 1u );
 
 		if ( timing ) HIPCHK( hipEventRecord( e[0], s ) );
@@ -1912,23 +1877,15 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 			HIPCHK( hipStreamWaitEvent( x, c->evHit[k], 0 ) );
 		}
 
-		if ( timing ) HIPCHK( hipEventRecord( e[4], x ) );
+		if ( timing ) HIPCHK( hipEventRecord( e[2], x ) );
 		if ( stats ) hipLaunchKernelGGL( k_shadow<true>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wx, k );
 		else hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wx, k );
-		if ( timing ) HIPCHK( hipEventRecord( e[5], x ) );
+		if ( timing ) HIPCHK( hipEventRecord( e[3], x ) );
 
-		if ( timing ) HIPCHK( hipEventRecord( e[2], s ) );
-		hipLaunchKernelGGL( k_spawn, dim3( gp ), dim3( RT_BLOCK ), 0, s, S, W, k );
-		if ( timing ) HIPCHK( hipEventRecord( e[3], s ) );
-		if ( overlap )
-		{
-			HIPCHK( hipEventRecord( c->evSpawn[k], s ) );
-			HIPCHK( hipStreamWaitEvent( x, c->evSpawn[k], 0 ) );
-		}
 
-		if ( timing ) HIPCHK( hipEventRecord( e[6], x ) );
+		if ( timing ) HIPCHK( hipEventRecord( e[4], x ) );
 		hipLaunchKernelGGL( k_light, dim3( gl ), dim3( RT_BLOCK ), 0, x, S, W, k );
-		if ( timing ) HIPCHK( hipEventRecord( e[7], x ) );
+		if ( timing ) HIPCHK( hipEventRecord( e[5], x ) );
 		if ( overlap ) HIPCHK( hipEventRecord( c->evLit[k], x ) );
 	}
 	if ( overlap )
@@ -2064,24 +2021,22 @@ int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 	for ( int f = 0; f < frames; ++f )
 	{
 		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
-		static const int dst[4] = { 0, 2, 1, 2 };     // closest, spawn, shadow, light
 		float t = 0.0f;
 		for ( int k = 0; k < n; ++k )
-			for ( int j = 0; j < 4; ++j )
+			for ( int j = 0; j < 3; ++j )             // closest, shadow, light
 			{
-				HIPCHK( hipEventElapsedTime( &t, ev[8 * k + 2 * j], ev[8 * k + 2 * j + 1] ) );
-				ms[dst[j]] += t;
+				HIPCHK( hipEventElapsedTime( &t, ev[6 * k + 2 * j], ev[6 * k + 2 * j + 1] ) );
+				ms[j] += t;
 			}
-		HIPCHK( hipEventElapsedTime( &t, ev[8 * RT_MAX_SLOTS], ev[8 * RT_MAX_SLOTS + 1] ) );
+		HIPCHK( hipEventElapsedTime( &t, ev[6 * RT_MAX_SLOTS], ev[6 * RT_MAX_SLOTS + 1] ) );
 		ms[3] += t;
-		HIPCHK( hipEventElapsedTime( &t, ev[8 * RT_MAX_SLOTS + 2], ev[8 * RT_MAX_SLOTS + 3] ) );
+		HIPCHK( hipEventElapsedTime( &t, ev[6 * RT_MAX_SLOTS + 2], ev[6 * RT_MAX_SLOTS + 3] ) );
 		ms[4] += t;
 	}
 	for ( int i = 0; i < 5; ++i ) ms[i] /= (float) frames;
-	launches[0] = launches[1] = n;
-	launches[2] = 2 * n;
+	launches[0] = launches[1] = launches[2] = n;
 	launches[3] = 1;
-	launches[4] = 4 * n + 1;
+	launches[4] = 3 * n + 1;
 	c->timedFrames = 0;
 	return 0;
 }
