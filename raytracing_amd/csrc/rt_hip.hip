@@ -51,8 +51,19 @@
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK  12     // traversal stack entries per lane kept in LDS
 #endif
+// Resident waves per SIMD the closest-hit kernel is compiled for.  It exists
+// twice: with 128 VGPRs (nothing spilled; the passes of a small frame are
+// chains of dependent loads and gain nothing from more waves) and with 96
+// (a little spilling, one more wave per SIMD and room beside it for the
+// shadow passes; faster from RT_BIG_FRAME pixels up).
 #ifndef RT_WAVES_CLOSEST
-#define RT_WAVES_CLOSEST 4   // resident waves per SIMD the closest-hit kernel is compiled for (128 VGPRs)
+#define RT_WAVES_CLOSEST 4
+#endif
+#ifndef RT_WAVES_CLOSEST_BIG
+#define RT_WAVES_CLOSEST_BIG 5
+#endif
+#ifndef RT_BIG_FRAME
+#define RT_BIG_FRAME ( 4u << 20 )
 #endif
 #ifndef RT_WAVES_SHADOW
 #define RT_WAVES_SHADOW  6   // the same for the shadow kernel (80 VGPRs)
@@ -61,7 +72,7 @@
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
 #define RT_TIMED_FRAMES 32
 #ifndef RT_AUX_OCC
-#define RT_AUX_OCC    2      // blocks per CU of a shadow pass that runs beside the closest-hit chain
+#define RT_AUX_OCC    4      // blocks per CU of a shadow pass that runs beside the closest-hit chain
 #endif
 #ifndef RT_TRAV_DYN
 #define RT_TRAV_DYN   8u     // eighths of a list the traversal passes hand out dynamically (8 = all but the first round)
@@ -925,8 +936,8 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 // ---------------------------------------------------------------------------
 // k_closest: closest-hit pass of one slot
 // ---------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__( RT_BLOCK, RT_WAVES_CLOSEST ) void k_closest( DevScene S, Work W, int slot, int wantIds )
+template <bool STATS, int WAVES>
+__global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work W, int slot, int wantIds )
 {
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
@@ -1368,7 +1379,8 @@ struct rt_hip_ctx
 	int treeDepth = 0;
 	int allocStack = 0;           // stack size the work buffers were sized for
 	bool workDirty = true;
-	int gridClosest[2] = { 0, 0 }, gridShadow[2] = { 0, 0 }, gridLight = 0;
+	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
+	int gridShadow[2] = { 0, 0 }, gridLight = 0;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[2] = { nullptr, nullptr };   // shadow + lighting passes (even / odd slots)
 	hipEvent_t evHit[RT_MAX_SLOTS] = {}, evLit[RT_MAX_SLOTS] = {};
@@ -1460,8 +1472,9 @@ rt_hip_ctx *rt_hip_create( int device )
 
 	// persistent grids: one resident wave set per CU, as many blocks as fit
 	int occ = 0;
-	struct { const void *f; int *dst; int *occ; } ks[5] = {
-		{ (const void *) k_closest<false>, &c->gridClosest[0], nullptr }, { (const void *) k_closest<true>, &c->gridClosest[1], nullptr },
+	struct { const void *f; int *dst; int *occ; } ks[7] = {
+		{ (const void *) k_closest<false, RT_WAVES_CLOSEST>, &c->gridClosest[0][0], nullptr }, { (const void *) k_closest<true, RT_WAVES_CLOSEST>, &c->gridClosest[0][1], nullptr },
+		{ (const void *) k_closest<false, RT_WAVES_CLOSEST_BIG>, &c->gridClosest[1][0], nullptr }, { (const void *) k_closest<true, RT_WAVES_CLOSEST_BIG>, &c->gridClosest[1][1], nullptr },
 		{ (const void *) k_shadow<false>, &c->gridShadow[0], &c->occShadow[0] }, { (const void *) k_shadow<true>, &c->gridShadow[1], &c->occShadow[1] },
 		{ (const void *) k_light, &c->gridLight, nullptr } };
 	for ( auto &k : ks )
@@ -1844,6 +1857,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
 	hipEvent_t *evFold = ev + 6 * RT_MAX_SLOTS, *evFrame = evFold + 2;
 	const bool overlap = c->overlap && S.stackSize > 1;
+	const bool big = W.npix >= RT_BIG_FRAME;
 	const int lights = S.nLights > 0 ? S.nLights : 1;
 
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
@@ -1860,7 +1874,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 
 		// a persistent grid never needs more waves than there are chunks
 		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
-		int gc = c->gridClosest[stats], gl = c->gridLight;
+		int gc = c->gridClosest[big][stats], gl = c->gridLight;
 		// beside the chain a shadow pass leaves part of every CU to it
 		int gw = overlap && c->occShadow[stats] > RT_AUX_OCC ? RT_AUX_OCC * c->numCU : c->gridShadow[stats];
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
@@ -1868,8 +1882,10 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		if ( k == 0 && want < (uint32_t) gl ) gl = (int) ( want ? want : 1u );
 
 		if ( timing ) HIPCHK( hipEventRecord( e[0], s ) );
-		if ( stats ) hipLaunchKernelGGL( k_closest<true>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
-		else hipLaunchKernelGGL( k_closest<false>, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
+		void ( *closest )( DevScene, Work, int, int ) = big
+			? ( stats ? k_closest<true, RT_WAVES_CLOSEST_BIG> : k_closest<false, RT_WAVES_CLOSEST_BIG> )
+			: ( stats ? k_closest<true, RT_WAVES_CLOSEST> : k_closest<false, RT_WAVES_CLOSEST> );
+		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
 		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
 		if ( overlap )
 		{
