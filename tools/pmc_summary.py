@@ -6,7 +6,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace(", ", ";")      # no commas inside a CSV field
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k][r["Counter_Name"]] += 1
 names = sorted({c for k in tot for c in tot[k]})
