@@ -74,6 +74,9 @@
 #ifndef RT_AUX_OCC
 #define RT_AUX_OCC    4      // blocks per CU of a shadow pass that runs beside the closest-hit chain
 #endif
+#ifndef RT_AUX_STREAMS
+#define RT_AUX_STREAMS 2      // auxiliary streams the shadow / lighting passes are dealt to
+#endif
 #ifndef RT_TRAV_DYN
 #define RT_TRAV_DYN   8u     // eighths of a list the traversal passes hand out dynamically (8 = all but the first round)
 #endif
@@ -1382,7 +1385,7 @@ struct rt_hip_ctx
 	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
 	int gridShadow[2] = { 0, 0 }, gridLight = 0;
 	int occShadow[2] = { 1, 1 };
-	hipStream_t aux[2] = { nullptr, nullptr };   // shadow + lighting passes (even / odd slots)
+	hipStream_t aux[RT_AUX_STREAMS] = {};        // shadow + lighting passes (slot k on stream k mod RT_AUX_STREAMS)
 	hipEvent_t evHit[RT_MAX_SLOTS] = {}, evLit[RT_MAX_SLOTS] = {};
 	int overlap = 1;
 	int workLights = -1;          // light count the shadow buffer was sized for
@@ -1795,8 +1798,8 @@ static int prepare_work( rt_hip_ctx *c )
 	if ( ensure( c, c->stackPos, sizeof( uint32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->hitId, sizeof( int32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->frame, sizeof( rt_argb ) * npix ) ) return 1;
-	// three strips: the closest-hit chain and one per auxiliary stream
-	if ( ensure( c, c->spill, 3 * sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
+	// one strip for the closest-hit chain and one per auxiliary stream
+	if ( ensure( c, c->spill, ( 1 + RT_AUX_STREAMS ) * sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
 	size_t per = cap * (size_t) ( slots > 1 ? slots - 1 : 1 );
 	W.ctr = (Counters *) c->ctr.p;
 	W.rayA = (float4 *) c->rays.p;
@@ -1867,10 +1870,10 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	for ( int k = 0; k < S.stackSize; ++k )
 	{
 		hipEvent_t *e = ev + 6 * k;
-		hipStream_t x = overlap ? c->aux[k & 1] : s;
+		hipStream_t x = overlap ? c->aux[k % RT_AUX_STREAMS] : s;
 		// every traversal running at the same time needs its own stack-overflow strip
 		Work Wx = W;
-		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + ( k & 1 ) ) * W.spillStride * RT_SPILL_CAP;
+		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + k % RT_AUX_STREAMS ) * W.spillStride * RT_SPILL_CAP;
 
 		// a persistent grid never needs more waves than there are chunks
 		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
