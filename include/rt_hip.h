@@ -93,7 +93,7 @@ typedef struct _rt_hip_stats
 #define RT_PARAM_MAX_PRIMS_IN_NODE 3   /* kd leaf size, default 7 (render pipe only)      */
 #define RT_PARAM_BUILD_THREADS     4   /* host builder threads, 0 = automatic             */
 #define RT_PARAM_TREE_CACHE        5   /* 1 = reuse the tree while geometry is unchanged  */
-#define RT_PARAM_GPU_BUILD         7   /* render pipe only: 1 = build the kd-tree on the GPU  */
+#define RT_PARAM_GPU_BUILD         7   /* render pipe only: kd-tree builder: 0 = host, 1 = GPU, 2 = GPU for scenes of 8192 triangles and more (default); same tree either way */
 #define RT_PARAM_OVERLAP           6   /* 0 = run every pass on one stream, in order (default 1:
                                           shadow + lighting passes on auxiliary streams)  */
 

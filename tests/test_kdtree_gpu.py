@@ -75,6 +75,6 @@ def test_headless_app_with_gpu_build_gives_the_same_frames(tmp_path):
         d = tmp_path / mode
         d.mkdir()
         args = [app, "--size", "256x160", "--squares", "50", "--frames", "2", "--dt", "0.3", "--format", "ppm", "--depth", "16"]
-        subprocess.run(args + (["--gpu-build"] if mode == "gpu" else []), cwd=d, check=True, capture_output=True, timeout=120)
+        subprocess.run(args + (["--gpu-build"] if mode == "gpu" else ["--host-build"]), cwd=d, check=True, capture_output=True, timeout=120)
         frames[mode] = [open(d / "pngs" / f"{i}.ppm", "rb").read() for i in range(2)]
     assert frames["host"] == frames["gpu"] and frames["host"][0] != frames["host"][1]
