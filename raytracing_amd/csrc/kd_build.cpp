@@ -182,14 +182,28 @@ struct Builder
 	int allAxes = 0;           // 1: try all three axes, keep the cheapest (not in the reference)
 	Pool pool;
 	size_t spawnThreshold = 2048;
+	// Running totals: triangles that cannot be separated double their references
+	// with every level, so a deep limit can ask for a tree far beyond the 30-bit
+	// links (and beyond memory).  Once a total passes the limit every further
+	// node becomes a leaf at once and the build is reported as failed.
+	std::atomic<uint64_t> madeNodes{ 1 }, leafRefs{ 0 };
+	std::atomic<bool> tooBig{ false };
+	static constexpr uint64_t LIMIT = 1ull << 30;
 
 	void split( BNode *node, std::vector<uint32_t> &prims, const rt_box &box, int depth, bool mayspawn )
 	{
 		const uint64_t n = prims.size();
+		if ( tooBig.load( std::memory_order_relaxed ) )
+		{
+			node->leaf = true;
+			return;
+		}
 		if ( n <= (uint64_t) maxPrims || depth == maxDepth )
 		{
 			node->leaf = true;
 			node->prims.swap( prims );
+			if ( leafRefs.fetch_add( n, std::memory_order_relaxed ) + n >= LIMIT )
+				tooBig.store( true, std::memory_order_relaxed );
 			return;
 		}
 		int ax = split_axis( box );
@@ -239,6 +253,8 @@ struct Builder
 		node->axis = ax;
 		node->l = new BNode();
 		node->r = new BNode();
+		if ( madeNodes.fetch_add( 2, std::memory_order_relaxed ) + 2 >= LIMIT )
+			tooBig.store( true, std::memory_order_relaxed );
 
 		if ( mayspawn && pr.size() >= spawnThreshold && pl.size() >= spawnThreshold )
 		{
@@ -296,6 +312,18 @@ void totals( BNode *n )
 	n->nodes = 1 + n->l->nodes + n->r->nodes;
 	n->refs = n->l->refs + n->r->refs;
 	n->depth = 1 + std::max( n->l->depth, n->r->depth );
+}
+
+void release_tree( BNode *n )
+{
+	if ( !n )
+		return;
+	if ( !n->leaf )
+	{
+		release_tree( n->l );
+		release_tree( n->r );
+	}
+	delete n;
 }
 
 // pre-order packing, left child right behind its parent (:860-912)
@@ -487,8 +515,11 @@ extern "C" int rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangl
 		b.worker();
 
 	totals( root );
-	if ( root->nodes >= ( 1ull << 30 ) || root->refs >= ( 1ull << 30 ) )
+	if ( b.tooBig.load() || root->nodes >= ( 1ull << 30 ) || root->refs >= ( 1ull << 30 ) )
+	{
+		release_tree( root );
 		return 4;          // 30-bit links of the 8-byte node
+	}
 	out->nNodes = root->nodes;
 	out->nRecs = root->refs;
 	out->nTris = nT;

@@ -1,0 +1,81 @@
+"""Randomised parity sweep of the HIP path against the CPU oracle (development
+helper; the committed tests hold a fixed subset): random triangle soups with
+spheres and lights, random materials (opaque / transparent / reflective),
+random tree limits, ray budgets, overlap on and off, band splits.
+Usage: python tools/stress_parity.py [first_seed] [count]"""
+import sys
+import numpy as np
+from oracle import orc
+from raytracing_amd import scenes
+from raytracing_amd import types as T
+from raytracing_amd.dist import band_rows
+from raytracing_amd.pipe import (RT_HIP_HITIDS, RT_HIP_STATS, RT_PARAM_OVERLAP, RT_PARAM_STACK_SIZE, FlatTree, HipRenderer)
+from tests.helpers import random_soup
+from raytracing_amd._lib import RtError  # noqa: F401
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.RandomState(seed)
+    w, h = int(rng.choice([64, 96, 130])), int(rng.choice([48, 70, 101]))
+    sc = scenes.Scene(f"stress{seed}", w, h, scenes.make_camera(w, h, hv=float(rng.uniform(0.3, 0.9))))
+    n = int(rng.choice([1, 30, 400, 3000]))
+    v, t = random_soup(n, seed, extent=float(rng.uniform(5, 30)), size=float(rng.uniform(1, 8)))
+    sc.meshes.append(scenes.Mesh(v, t, 0))
+    sc.flatten = lambda v=v, t=t: (v, t)        # keep the per-triangle materials 0..2
+    for m in range(3):
+        alpha = float(rng.choice([1.0, 1.0, 0.6, 0.3, 0.0]))
+        refl = float(rng.choice([0.0, 0.4, 0.8]))
+        sc.materials[m] = T.make_material((alpha, *rng.uniform(0.2, 1.0, 3)), (0.0, 0.05, 0.05, 0.05), (0.0, 0.6, 0.6, 0.6),
+                                          (float(rng.uniform(2, 30)), 0.4, 0.4, 0.4), (0.0, refl, refl, refl),
+                                          float(rng.choice([0.0, 0.02, 0.2])), float(rng.choice([1.0, 1.33, 1.6])))
+    sc.spheres += [scenes.make_sphere(rng.uniform(-20, 20, 3) + (0, 0, 60), float(rng.uniform(2, 9)), int(rng.randint(3)))
+                   for _ in range(int(rng.randint(0, 4)))]
+    sc.lights += [scenes.make_light(rng.uniform(-40, 40, 3), float(rng.uniform(30, 120))) for _ in range(int(rng.randint(0, 4)))]
+    sc.stack_size = int(rng.randint(1, 7))
+    depth, prims = int(rng.choice([0, 4, 10, 20, 30])), int(rng.choice([1, 3, 7, 12, 40]))
+    vv, tt = sc.flatten()
+    if prims <= 3 and n >= 3000:
+        depth = min(depth, 16)      # overlapping triangles cannot be separated: references double per level
+    try:
+        tree = FlatTree.build(vv, tt, depth, prims)
+    except Exception as e:          # tree beyond the 30-bit links: a legitimate refusal
+        print(f"seed {seed}: tris {n} depth {depth} leaf {prims}: {e}", flush=True)
+        continue
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    r = HipRenderer(0)
+    r.load_scene(sc, tree)
+    r.set_param(RT_PARAM_STACK_SIZE, sc.stack_size)
+    ok = True
+    for overlap in (1, 0):
+        r.set_param(RT_PARAM_OVERLAP, overlap)
+        r.set_tile(16, 1, 0)
+        r.render(RT_HIP_HITIDS | RT_HIP_STATS)
+        img, ids, st = r.read_frame(), r.read_hit_ids(), r.stats()
+        same = (ids == oid).mean()
+        d = np.abs(img.astype(int) - oimg.astype(int)).max()
+        rays = (st["raysClosest"], st["raysShadow"]) == (ost["raysClosest"], ost["raysShadow"])
+        if same < 1.0 or d > 0 or not rays:
+            ok = False
+            print(f"seed {seed} overlap {overlap}: ids {same:.5f} maxdiff {d} rays {rays} ({st['raysClosest']},{st['raysShadow']}) vs ({ost['raysClosest']},{ost['raysShadow']})", flush=True)
+    parts = int(rng.choice([2, 3, 5]))
+    band = int(rng.choice([4, 16]))
+    full = np.zeros_like(oimg)
+    r.set_param(RT_PARAM_OVERLAP, 1)
+    for p in range(parts):
+        r.set_tile(band, parts, p)
+        r.render(0)
+        rows = band_rows(h, band, parts, p)
+        if len(rows):
+            full[rows] = r.read_frame()[:len(rows)]
+    if not np.array_equal(full, img):
+        ok = False
+        print(f"seed {seed}: band split {band}x{parts} differs from the full frame", flush=True)
+    r.close()
+    tree.release()
+    bad += not ok
+    print(f"seed {seed}: {w}x{h} tris {n} spheres {len(sc.spheres)} lights {len(sc.lights)} stack {sc.stack_size} depth {depth} leaf {prims}: {'ok' if ok else 'MISMATCH'}", flush=True)
+print("mismatching seeds:", bad)
+sys.exit(1 if bad else 0)
