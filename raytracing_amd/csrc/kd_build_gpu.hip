@@ -7,9 +7,9 @@
 //   k_decide    node  : leaf (count <= maxPrims or depth == maxDepth) or split axis + candidate planes
 //   k_hist      ref   : histogram of every triangle extent against the 32 planes of its node
 //   k_split     node  : counts left / right of every plane, SAH cost, lowest-index minimum
-//   scans       node  : child node numbers, child reference ranges, leaf pool ranges (hipCUB)
+//   scan        node  : child node numbers, child reference ranges, leaf pool ranges (one hipCUB scan over triples)
 //   k_children  node  : child boxes, next level's node table, this node's record of the tree
-//   k_flags + scan + k_scatter  ref : STABLE partition of the triangle references
+//   scan of flags + k_scatter   ref : STABLE partition of the triangle references
 //                       (a reference goes left if min < sep, right if max > sep, possibly both)
 // then, over the finished tree: sub-tree sizes bottom-up, pre-order positions
 // top-down (left child = own index + 1), nodes + leaf records + shading records.
@@ -115,8 +115,26 @@ struct NodeWork            // per node of the current level
 	float *sep;
 	uint32_t *cntL, *cntR;
 	uint32_t *childRefs, *leafCnt;
-	uint32_t *splitIdx, *childStart, *leafStart;    // exclusive scans of split / childRefs / leafCnt
+	struct Trip *incl;     // inclusive scan of (split, childRefs, leafCnt), one pass for the three
+	__device__ uint32_t splitIdx( uint32_t i ) const;
+	__device__ uint32_t childStart( uint32_t i ) const;
+	__device__ uint32_t leafStart( uint32_t i ) const;
 };
+
+struct alignas( 16 ) Trip { uint32_t a, b, c, d; };
+struct TripSum
+{
+	__host__ __device__ Trip operator()( const Trip &x, const Trip &y ) const { return Trip{ x.a + y.a, x.b + y.b, x.c + y.c, 0u }; }
+};
+struct TripLoad
+{
+	const uint32_t *a, *b, *c;
+	__host__ __device__ Trip operator()( uint32_t i ) const { return Trip{ a[i], b[i], c[i], 0u }; }
+};
+// exclusive values = inclusive value - own contribution
+__device__ inline uint32_t NodeWork::splitIdx( uint32_t i ) const { return incl[i].a - split[i]; }
+__device__ inline uint32_t NodeWork::childStart( uint32_t i ) const { return incl[i].b - childRefs[i]; }
+__device__ inline uint32_t NodeWork::leafStart( uint32_t i ) const { return incl[i].c - leafCnt[i]; }
 
 __device__ inline float box_c( const float *b, int ax ) { return b[ax]; }
 __device__ inline float box_e( const float *b, int ax ) { return b[3 + ax]; }
@@ -269,17 +287,6 @@ __global__ __launch_bounds__( TB ) void k_split( LevelTab L, NodeWork W, uint32_
 	W.childRefs[i] = (uint32_t) ( cl + cr );
 }
 
-// totals of the three scans -> host (3 words)
-__global__ void k_totals( NodeWork W, uint32_t n, uint32_t *out )
-{
-	if ( threadIdx.x == 0 && blockIdx.x == 0 )
-	{
-		out[0] = W.splitIdx[n - 1] + W.split[n - 1];
-		out[1] = W.childStart[n - 1] + W.childRefs[n - 1];
-		out[2] = W.leafStart[n - 1] + W.leafCnt[n - 1];
-	}
-}
-
 // child boxes: slab split at sep (:1034-1073); record of the node in level order
 __global__ __launch_bounds__( TB ) void k_children( LevelTab L, NodeWork W, LevelTab N, uint32_t n, uint2 *info, uint32_t idBase,
 	uint32_t nextBase, uint32_t leafPoolBase )
@@ -289,13 +296,13 @@ __global__ __launch_bounds__( TB ) void k_children( LevelTab L, NodeWork W, Leve
 		return;
 	if ( !W.split[i] )
 	{
-		info[idBase + i] = make_uint2( leafPoolBase + W.leafStart[i], ( L.count[i] << 2 ) | 3u );
+		info[idBase + i] = make_uint2( leafPoolBase + W.leafStart( i ), ( L.count[i] << 2 ) | 3u );
 		return;
 	}
 	const float *b = L.box + 6ull * i;
 	const int ax = (int) W.axis[i];
 	const float sep = W.sep[i];
-	const uint32_t c = 2u * W.splitIdx[i];
+	const uint32_t c = 2u * W.splitIdx( i );
 	float *bl = N.box + 6ull * c, *br = bl + 6;
 	for ( int k = 0; k < 6; ++k )
 		bl[k] = br[k] = b[k];
@@ -303,58 +310,63 @@ __global__ __launch_bounds__( TB ) void k_children( LevelTab L, NodeWork W, Leve
 	bl[3 + ax] = 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) );
 	br[ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep );
 	br[3 + ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep );
-	N.start[c] = W.childStart[i];
+	N.start[c] = W.childStart( i );
 	N.count[c] = W.cntL[i];
-	N.start[c + 1] = W.childStart[i] + W.cntL[i];
+	N.start[c + 1] = W.childStart( i ) + W.cntL[i];
 	N.count[c + 1] = W.cntR[i];
 	info[idBase + i] = make_uint2( __float_as_uint( sep ), ( ( nextBase + c ) << 2 ) | (uint32_t) ax );
 }
 
-// per reference: goes left (low word) / right (high word)
-__global__ __launch_bounds__( TB ) void k_flags( NodeWork W, const uint32_t *refs, const uint32_t *refNode, uint32_t nRefs,
-	const float *ext, uint32_t nT, unsigned long long *flags )
+// per reference: goes left (low word) / right (high word); evaluated on the
+// fly by the scan and again by the scatter, never stored
+struct RefFlags
 {
-	const uint32_t j = blockIdx.x * TB + threadIdx.x;
-	if ( j >= nRefs )
-		return;
-	const uint32_t i = refNode[j];
-	unsigned long long f = 0ull;
-	if ( W.split[i] )
+	NodeWork W;
+	const uint32_t *refs, *refNode;
+	const float *ext;
+	uint32_t nT;
+	__host__ __device__ unsigned long long operator()( uint32_t j ) const
 	{
-		const uint32_t ax = W.axis[i], tri = refs[j];
-		const float sep = W.sep[i];
-		if ( ext[(size_t) ax * nT + tri] < sep ) f |= 1ull;
-		if ( ext[( 3ull + ax ) * nT + tri] > sep ) f |= 1ull << 32;
+		const uint32_t i = refNode[j];
+		unsigned long long f = 0ull;
+		if ( W.split[i] )
+		{
+			const uint32_t ax = W.axis[i], tri = refs[j];
+			const float sep = W.sep[i];
+			if ( ext[(size_t) ax * nT + tri] < sep ) f |= 1ull;
+			if ( ext[( 3ull + ax ) * nT + tri] > sep ) f |= 1ull << 32;
+		}
+		return f;
 	}
-	flags[j] = f;
-}
+};
 
 // stable partition (:971-1029): the k-th reference of a node that goes left
 // becomes the k-th reference of its left child; leaves move to the leaf pool
-__global__ __launch_bounds__( TB ) void k_scatter( LevelTab L, NodeWork W, const uint32_t *refs, const uint32_t *refNode, uint32_t nRefs,
-	const unsigned long long *flags, const unsigned long long *scan, uint32_t *nextRefs, uint32_t *nextRefNode,
+__global__ __launch_bounds__( TB ) void k_scatter( LevelTab L, RefFlags F, uint32_t nRefs,
+	const unsigned long long *scan, uint32_t *nextRefs, uint32_t *nextRefNode,
 	uint32_t *leafPool, uint32_t leafPoolBase )
 {
 	const uint32_t j = blockIdx.x * TB + threadIdx.x;
 	if ( j >= nRefs )
 		return;
-	const uint32_t i = refNode[j], tri = refs[j], s0 = L.start[i];
+	const NodeWork &W = F.W;
+	const uint32_t i = F.refNode[j], tri = F.refs[j], s0 = L.start[i];
 	if ( !W.split[i] )
 	{
-		leafPool[leafPoolBase + W.leafStart[i] + ( j - s0 )] = tri;
+		leafPool[leafPoolBase + W.leafStart( i ) + ( j - s0 )] = tri;
 		return;
 	}
-	const unsigned long long f = flags[j], here = scan[j], base = scan[s0];
-	const uint32_t c = 2u * W.splitIdx[i];
+	const unsigned long long f = F( j ), here = scan[j], base = scan[s0];
+	const uint32_t c = 2u * W.splitIdx( i );
 	if ( f & 1ull )
 	{
-		const uint32_t p = W.childStart[i] + ( (uint32_t) here - (uint32_t) base );
+		const uint32_t p = W.childStart( i ) + ( (uint32_t) here - (uint32_t) base );
 		nextRefs[p] = tri;
 		nextRefNode[p] = c;
 	}
 	if ( f >> 32 )
 	{
-		const uint32_t p = W.childStart[i] + W.cntL[i] + ( (uint32_t) ( here >> 32 ) - (uint32_t) ( base >> 32 ) );
+		const uint32_t p = W.childStart( i ) + W.cntL[i] + ( (uint32_t) ( here >> 32 ) - (uint32_t) ( base >> 32 ) );
 		nextRefs[p] = tri;
 		nextRefNode[p] = c + 1u;
 	}
@@ -488,11 +500,11 @@ void scene_box( const rt_vertex *verts, uint64_t n, rt_box &bbox )
 
 struct Scratch
 {
-	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, flags, scan, cub, info, leafPool, work, sub, order, totals;
+	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, scan, cub, info, leafPool, work, sub, order;
 	uint32_t *hTotals = nullptr;
 	void release()
 	{
-		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &flags, &scan, &cub, &info, &leafPool, &work, &sub, &order, &totals } )
+		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &scan, &cub, &info, &leafPool, &work, &sub, &order } )
 			v->release();
 		if ( hTotals ) (void) hipHostFree( hTotals );
 		hTotals = nullptr;
@@ -515,8 +527,9 @@ int level_tab( DVec &buf, size_t n, hipStream_t s, LevelTab &t )
 int node_work( DVec &buf, size_t n, hipStream_t s, NodeWork &w )
 {
 	if ( n == 0 ) n = 1;
-	if ( int rc = buf.reserve( n * ( 66 + 14 ) * sizeof( uint32_t ), s ) ) return rc;
+	if ( int rc = buf.reserve( n * ( 4 + 66 + 11 ) * sizeof( uint32_t ), s ) ) return rc;
 	uint32_t *p = buf.as<uint32_t>();
+	w.incl = (Trip *) p; p += 4 * n;          // first: 16-byte aligned
 	w.hist = p; p += 66 * n;
 	w.split = p; p += n;
 	w.axis = p; p += n;
@@ -528,14 +541,11 @@ int node_work( DVec &buf, size_t n, hipStream_t s, NodeWork &w )
 	w.cntR = p; p += n;
 	w.childRefs = p; p += n;
 	w.leafCnt = p; p += n;
-	w.splitIdx = p; p += n;
-	w.childStart = p; p += n;
-	w.leafStart = p; p += n;
 	return 0;
 }
 
-template <class T>
-int exclusive_sum( DVec &cub, const T *in, T *out, size_t n, hipStream_t s )
+template <class In, class T>
+int exclusive_sum( DVec &cub, In in, T *out, size_t n, hipStream_t s )
 {
 	size_t bytes = 0;
 	GCHK( hipcub::DeviceScan::ExclusiveSum( nullptr, bytes, in, out, (int) n, s ) );
@@ -634,8 +644,6 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 	if ( !S.hTotals )
 		GCHK( hipHostMalloc( (void **) &S.hTotals, 3 * sizeof( uint32_t ), hipHostMallocDefault ) );
 	uint32_t *hTotals = S.hTotals;
-	DVec &totalsDev = S.totals;
-	if ( int rc = totalsDev.reserve( 16, s ) ) return rc;
 
 	std::vector<uint32_t> levelFirst, levelCount;
 	uint64_t nodesTotal = 0, leafRefs = 0;
@@ -654,11 +662,16 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 		if ( levelRefs )
 			hipLaunchKernelGGL( k_hist, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, W, refs, refNode, levelRefs, S.ext.as<float>(), nT );
 		hipLaunchKernelGGL( k_split, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, levelNodes );
-		if ( int rc = exclusive_sum( S.cub, W.split, W.splitIdx, levelNodes, s ) ) return rc;
-		if ( int rc = exclusive_sum( S.cub, W.childRefs, W.childStart, levelNodes, s ) ) return rc;
-		if ( int rc = exclusive_sum( S.cub, W.leafCnt, W.leafStart, levelNodes, s ) ) return rc;
-		hipLaunchKernelGGL( k_totals, dim3( 1 ), dim3( 64 ), 0, s, W, levelNodes, totalsDev.as<uint32_t>() );
-		GCHK( hipMemcpyAsync( hTotals, totalsDev.p, 3 * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+		{
+			hipcub::TransformInputIterator<Trip, TripLoad, hipcub::CountingInputIterator<uint32_t>> in(
+				hipcub::CountingInputIterator<uint32_t>( 0u ), TripLoad{ W.split, W.childRefs, W.leafCnt } );
+			size_t bytes = 0;
+			GCHK( hipcub::DeviceScan::InclusiveScan( nullptr, bytes, in, W.incl, TripSum(), (int) levelNodes, s ) );
+			if ( int rc = S.cub.reserve( bytes ? bytes : 16, s ) ) return rc;
+			GCHK( hipcub::DeviceScan::InclusiveScan( S.cub.p, bytes, in, W.incl, TripSum(), (int) levelNodes, s ) );
+		}
+		// the last inclusive value holds the three totals
+		GCHK( hipMemcpyAsync( hTotals, W.incl + ( levelNodes - 1 ), 3 * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
 		GCHK( hipStreamSynchronize( s ) );
 		const uint32_t splits = hTotals[0], childRefs = hTotals[1], levelLeafRefs = hTotals[2];
 		if ( (uint64_t) splits * 2 + nodesTotal + levelNodes >= ( 1ull << 30 ) || leafRefs + levelLeafRefs + childRefs >= ( 1ull << 30 ) )
@@ -676,13 +689,13 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 			(uint32_t) nodesTotal, (uint32_t) ( nodesTotal + levelNodes ), (uint32_t) leafRefs );
 		if ( levelRefs )
 		{
-			if ( int rc = S.flags.reserve( sizeof( unsigned long long ) * levelRefs, s ) ) return rc;
 			if ( int rc = S.scan.reserve( sizeof( unsigned long long ) * levelRefs, s ) ) return rc;
-			hipLaunchKernelGGL( k_flags, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, W, refs, refNode, levelRefs, S.ext.as<float>(), nT,
-				S.flags.as<unsigned long long>() );
-			if ( int rc = exclusive_sum( S.cub, S.flags.as<unsigned long long>(), S.scan.as<unsigned long long>(), levelRefs, s ) ) return rc;
-			hipLaunchKernelGGL( k_scatter, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, cur, W, refs, refNode, levelRefs,
-				S.flags.as<unsigned long long>(), S.scan.as<unsigned long long>(), nRefs, nRefNode, S.leafPool.as<uint32_t>(), (uint32_t) leafRefs );
+			const RefFlags F{ W, refs, refNode, S.ext.as<float>(), nT };
+			hipcub::TransformInputIterator<unsigned long long, RefFlags, hipcub::CountingInputIterator<uint32_t>> in(
+				hipcub::CountingInputIterator<uint32_t>( 0u ), F );
+			if ( int rc = exclusive_sum( S.cub, in, S.scan.as<unsigned long long>(), levelRefs, s ) ) return rc;
+			hipLaunchKernelGGL( k_scatter, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, cur, F, levelRefs,
+				S.scan.as<unsigned long long>(), nRefs, nRefNode, S.leafPool.as<uint32_t>(), (uint32_t) leafRefs );
 		}
 
 		nodesTotal += levelNodes;
