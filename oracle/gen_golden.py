@@ -16,6 +16,7 @@ import hashlib
 import json
 import math
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -135,6 +136,9 @@ def main():
     with open(os.path.join(GOLD, "ref_host_math.json"), "w") as f:
         json.dump(hm, f)
 
+    # 4b. OBJ / MTL loader of the reference on the inputs of oracle/obj_cases.py
+    write_obj_golden()
+
     # 5. regression vectors of the kernel restatement
     for name, (sc, depth, prims) in image_scenes().items():
         v, t = sc.flatten()
@@ -146,5 +150,26 @@ def main():
         print("orc image", name, img.shape, st)
 
 
+def write_obj_golden():
+    """tests/golden/ref_obj_loader.json: what the reference's rt_mesh_load_from_obj
+    (rt_meshes.c:136-340) returns for oracle/obj_cases.py's OBJ + MTL pair
+    (floats as bit patterns).  The inputs are this repository's own text."""
+    import tempfile
+    from oracle import obj_cases as oc
+    d = tempfile.mkdtemp()
+    oc.write_case(d)
+    rc, m = oc.load(ref.lib(), d, "case.obj")
+    assert rc == 0
+    bits = lambda a: np.asarray(a, np.float32).view(np.uint32).tolist()
+    out = dict(pos=bits(m["pos"]), norm=bits(m["norm"]), tris=m["tris"].tolist(), groups=m["groups"],
+               mats=[{k: (bits(v) if isinstance(v, list) else bits([v])[0]) for k, v in mt.items()} for mt in m["mats"]])
+    with open(os.path.join(GOLD, "ref_obj_loader.json"), "w") as f:
+        json.dump(out, f)
+    print("obj loader golden:", len(m["tris"]), "triangles", len(m["groups"]), "groups", len(m["mats"]), "materials")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "obj":
+        write_obj_golden()
+    else:
+        main()

@@ -382,3 +382,44 @@ def test_very_large_leaves(depth, prims):
     same, exact = assert_parity(img, ids, oimg, oid)
     assert same == 1.0 and exact >= 0.999
     assert st["raysClosest"] == ost["raysClosest"] and st["raysShadow"] == ost["raysShadow"]
+
+
+def test_mesh_add_group_feeds_the_pipe_like_explicit_adds(tmp_path):
+    """rt_mesh_add_group (rt_meshes.c:352-378) = the group's material into the
+    slot + the group's vertex / triangle range into the pipe."""
+    import ctypes as C
+    from oracle import obj_cases as oc
+    from raytracing_amd._lib import lib
+    oc.write_case(str(tmp_path))
+    L = lib()
+    m = oc.Mesh()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert L.rt_mesh_load_from_obj(C.byref(m), b"case.obj") == 0
+    finally:
+        os.chdir(cwd)
+    rc, data = oc.load(L, str(tmp_path), "case.obj")
+    v = np.frombuffer((C.c_char * (m.vc * T.vertex.itemsize)).from_address(m.v), T.vertex).copy()
+    t = np.frombuffer((C.c_char * (m.tc * T.triangle.itemsize)).from_address(m.t), T.triangle).copy()
+    mats = np.frombuffer((C.c_char * (m.mc * T.material.itemsize)).from_address(m.mat), T.material).copy()
+    world = np.eye(4, dtype=np.float32)
+    world[3, :3] = (1.5, 0.5, -6.0)             # row-vector convention: translation in the last row
+    cam = scenes.make_camera(96, 64, hv=0.5, world=world)
+    frames = []
+    for mode in ("groups", "explicit"):
+        rp = RenderPipe(96, 64)
+        rp.set_camera(cam)
+        rp.add_light(scenes.make_light((2.0, -3.0, -4.0), 20.0))
+        if mode == "groups":
+            for g in range(m.gc):
+                L.rt_mesh_add_group(C.byref(rp._rp), C.byref(m), C.c_uint64(g), C.c_uint64(g))
+        else:
+            for g, (mi, vo, to, vc, tc) in enumerate(data["groups"]):
+                rp.add_material(mats[mi], g)
+                rp.add_triangles(v, t, vo, to, vc, tc, g)
+        assert rp.counts["triangles"] == 7 and rp.counts["vertices"] == 9
+        frames.append(rp.draw())
+        rp.cleanup()
+    L.rt_mesh_release(C.byref(m))
+    assert np.array_equal(frames[0], frames[1]) and frames[0].max() > 0
