@@ -423,3 +423,65 @@ def test_mesh_add_group_feeds_the_pipe_like_explicit_adds(tmp_path):
         rp.cleanup()
     L.rt_mesh_release(C.byref(m))
     assert np.array_equal(frames[0], frames[1]) and frames[0].max() > 0
+
+
+def test_block_counters_grow_and_reset_like_the_reference():
+    """The block accounting of rt_add_block (rt_funcs_render_pipe.c:186-207) and
+    its call sites (:215-367): which add makes which counter grow, and
+    rt_render_pipe_reset_blocks (:111-125) puts everything back to one block."""
+    rp = RenderPipe(32, 24)
+    s = rp._rp
+    blocks = lambda: (s.primBlocks, s.primDecsBlocks, s.lightBlocks, s.lightDecsBlocks, s.triangleBlocks, s.vertexBlocks, s.materialBlocks)
+    assert blocks() == (1,) * 7
+    # lights: 48-byte records in 1024-byte blocks grow when end + 48 >= 1024 * blocks (the 22nd light: 21 * 48 + 48 = 1056),
+    # descriptors in blocks of 32 grow with the 33rd
+    for i in range(33):
+        rp.add_light(scenes.make_light((float(i), -30.0, 0.0), 50.0))
+        want = (2 if i >= 21 else 1, 2 if i >= 32 else 1)
+        assert (s.lightBlocks, s.lightDecsBlocks) == want, i
+    assert s.lightsCount == 33 and s.lightsEnd == 33 * T.point_light.itemsize
+    # materials: slot 127 fits the first block, slot 128 needs the second
+    mat = T.make_material((1.0, 0.5, 0.5, 0.5), (0, .1, .1, .1), (0, .5, .5, .5), (5.0, .2, .2, .2), (0, 0, 0, 0), 0.0, 1.0)
+    rp.add_material(mat, 127)
+    assert s.materialBlocks == 1
+    rp.add_material(mat, 128)
+    assert s.materialBlocks == 2
+    # triangles / vertices: grow when count + added >= 1048576 * blocks, by added / 1048576 blocks (at least one)
+    v, t = random_soup(4, 1)
+    big_t = np.zeros(1048575, T.triangle)
+    big_t["pV1"], big_t["pV2"] = 1, 2
+    rp.add_triangles(v, big_t, 0, 0, 3, len(big_t), 0)
+    assert (s.triangleBlocks, s.vertexBlocks, s.trianglesCount, s.vertexCount) == (1, 1, 1048575, 3)
+    rp.add_triangles(v, t, 0, 0, 3, 1, 0)
+    assert (s.triangleBlocks, s.trianglesCount, s.vertexCount) == (2, 1048576, 6)
+    rp.add_triangles(v, np.concatenate([big_t, big_t, big_t[:5]]), 0, 0, 3, 2 * 1048575 + 5, 0)
+    assert s.triangleBlocks == 4                       # 2 + (2097155 / 1048576 = 2)
+    # spheres: 32-byte records in 32 MiB blocks, descriptors in blocks of 1048576
+    rp.add_primitive(scenes.make_sphere((0.0, 0.0, 50.0), 3.0, 0))
+    assert (s.primBlocks, s.primDecsBlocks, s.primsCount, s.primsEnd) == (1, 1, 1, T.sphere.itemsize)
+    import ctypes
+    rp._L.rt_render_pipe_reset_blocks(ctypes.byref(s))
+    assert blocks() == (1,) * 7
+    assert (s.trianglesCount, s.vertexCount, s.lightsCount, s.primsCount, s.lightsEnd, s.primsEnd) == (0,) * 6
+    rp.cleanup()
+
+
+def test_material_slots_beyond_the_first_block_and_many_lights_render_like_the_oracle():
+    sc = edge_scene("few_tris")
+    sc.materials[200] = sc.materials[0]
+    v, t = sc.flatten()
+    t = t.copy()
+    t["mat"] = 200
+    sc.meshes = [scenes.Mesh(v, t, 200)]
+    sc.lights = [scenes.make_light((-5.0 + 0.3 * i, -10.0, 0.1 * i), 30.0 / 40.0) for i in range(40)]
+    rp = RenderPipe(sc.w, sc.h)
+    rp.set_camera(sc.camera)
+    rp.add_scene(sc)
+    assert rp._rp.materialBlocks == 2 and rp._rp.lightDecsBlocks == 2
+    img = rp.draw()
+    rp.cleanup()
+    vv, tt = sc.flatten()
+    tree = FlatTree.build(vv, tt)
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    assert np.abs(img.astype(int) - oimg.astype(int)).max() <= 1 and img.max() > 0
