@@ -136,6 +136,9 @@ def main():
     with open(os.path.join(GOLD, "ref_host_math.json"), "w") as f:
         json.dump(hm, f)
 
+    # 4a. every function of rt_funcs_math.h / rt_funcs_primitives.h on the seeded call table
+    write_math_golden()
+
     # 4b. OBJ / MTL loader of the reference on the inputs of oracle/obj_cases.py
     write_obj_golden()
 
@@ -148,6 +151,16 @@ def main():
                             depth=depth, prims=prims, img=img, hit=hit,
                             stats=np.array([st[k] for k in ("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits")], np.uint64))
         print("orc image", name, img.shape, st)
+
+
+def write_math_golden():
+    """tests/golden/ref_math_table.json: outputs of the reference's host math and
+    constructors on oracle/math_cases.py's call table (bit patterns)."""
+    from oracle import math_cases as mc
+    out = mc.run_all(ref.lib(), skip=mc.NOT_RUNNABLE_IN_REFERENCE)
+    with open(os.path.join(GOLD, "ref_math_table.json"), "w") as f:
+        json.dump(dict(cases=mc.CASES, results=out), f)
+    print("math table golden:", len(out), "functions x", mc.CASES, "cases")
 
 
 def write_obj_golden():
@@ -171,5 +184,7 @@ def write_obj_golden():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "obj":
         write_obj_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "math":
+        write_math_golden()
     else:
         main()

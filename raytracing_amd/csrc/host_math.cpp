@@ -114,7 +114,8 @@ void rt_matrix3_create_scale( rt_matrix3 *pR, rt_float x, rt_float y, rt_float z
 void rt_matrix3_create_rotate( rt_matrix3 *pR, rt_float ang, RT_AXIS a )
 {
 	if ( !pR ) exit( -1 );
-	const float c = (float) cos( ang ), s = (float) sin( ang ), ns = (float) -sin( ang );
+	// the reference is C: cos / sin / tan of a float are the DOUBLE functions there, rounded on assignment
+	const float c = (float) cos( (double) ang ), s = (float) sin( (double) ang ), ns = (float) -sin( (double) ang );
 	if ( a == RT_AXIS_X )
 	{
 		pR->_11 = 1; pR->_12 = 0; pR->_13 = 0;
@@ -146,7 +147,8 @@ void rt_matrix4_create_scale( rt_matrix4 *pR, rt_float x, rt_float y, rt_float z
 void rt_matrix4_create_rotate( rt_matrix4 *pR, rt_float ang, RT_AXIS a )
 {
 	if ( !pR ) exit( -1 );
-	const float c = (float) cos( ang ), s = (float) sin( ang ), ns = (float) -sin( ang );
+	// the reference is C: cos / sin / tan of a float are the DOUBLE functions there, rounded on assignment
+	const float c = (float) cos( (double) ang ), s = (float) sin( (double) ang ), ns = (float) -sin( (double) ang );
 	if ( a == RT_AXIS_X )
 	{
 		const float r[16] = { 1, 0, 0, 0,  0, c, s, 0,  0, ns, c, 0,  0, 0, 0, 1 };
@@ -167,8 +169,10 @@ void rt_matrix4_create_rotate( rt_matrix4 *pR, rt_float ang, RT_AXIS a )
 // maps NDC x,y in [-1,1] to the view plane at z = 1 (reference :127-137)
 void rt_matrix4_create_projection( rt_matrix4 *pR, rt_float asp, rt_float hV )
 {
-	const float sx = (float) ( 2.0f * tan( hV / 2.0f ) * asp );
-	const float sy = (float) ( 2.0f * tan( hV / 2.0f ) );
+	// C semantics: tan( double ), products in double, one rounding on assignment
+	const double t = tan( (double) ( hV / 2.0f ) );
+	const float sx = (float) ( 2.0 * t * (double) asp );
+	const float sy = (float) ( 2.0 * t );
 	const float r[16] = { sx, 0, 0, 0,  0, sy, 0, 0,  0, 0, 1, 0,  0, 0, 0, 1 };
 	set_rows( pR, r );
 }
