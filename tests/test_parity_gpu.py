@@ -485,3 +485,64 @@ def test_material_slots_beyond_the_first_block_and_many_lights_render_like_the_o
     nodes, idx = tree.expand()
     oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
     assert np.abs(img.astype(int) - oimg.astype(int)).max() <= 1 and img.max() > 0
+
+
+def test_get_camera_lends_the_pipe_camera_and_draw_device_fills_a_device_buffer():
+    """rt_render_pipe_get_camera / _free_camera (rt_funcs_render_pipe.c:369-387):
+    the caller edits the pipe's own camera in place.  rt_render_pipe_draw_device
+    (no reference counterpart) leaves the frame in HBM."""
+    import ctypes
+    import torch
+    sc, depth, prims = IMG["default_small"]
+    frames = []
+    for mode in ("set", "edit_in_place", "device"):
+        rp = RenderPipe(sc.w, sc.h)
+        cam = np.array(sc.camera, T.camera)
+        moved = cam.copy()
+        moved["world"][3, 0] += 3.0
+        if mode == "edit_in_place":
+            rp.set_camera(cam)
+            p = ctypes.c_void_p()
+            rp._L.rt_render_pipe_get_camera(ctypes.byref(rp._rp), ctypes.byref(p))
+            lent = np.frombuffer((ctypes.c_char * T.camera.itemsize).from_address(p.value), T.camera)
+            assert lent.tobytes() == cam.tobytes()
+            lent["world"][0][3, 0] += 3.0
+            rp._L.rt_render_pipe_free_camera(ctypes.byref(rp._rp), p)
+        else:
+            rp.set_camera(moved)
+        rp.add_scene(sc)
+        if mode == "device":
+            out = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda:0")
+            rp._L.rt_render_pipe_draw_device(ctypes.byref(rp._rp), ctypes.c_void_p(out.data_ptr()))
+            rp._L.rt_hip_sync(ctypes.c_void_p(rp._L.rt_render_pipe_hip(ctypes.byref(rp._rp))))
+            frames.append(out.cpu().numpy())
+            assert rp.counts == dict(triangles=0, vertices=0, prims=0, lights=0)     # consumed like draw
+        else:
+            frames.append(rp.draw())
+        rp.cleanup()
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    z = np.load(os.path.join(GOLD, "orc_default_small.npz"))
+    assert not np.array_equal(frames[0], z["img"])          # the camera really moved
+
+
+def test_page_locked_host_block_and_builder_scratch_trim():
+    import ctypes
+    from raytracing_amd._lib import lib
+    from raytracing_amd.pipe import DeviceTree
+    L = lib()
+    r = HipRenderer(0)
+    L.rt_hip_alloc_host.restype = ctypes.c_void_p
+    p = L.rt_hip_alloc_host(r._c, ctypes.c_size_t(1 << 20))
+    assert p
+    ctypes.memset(p, 0x5a, 1 << 20)
+    L.rt_hip_free_host(r._c, ctypes.c_void_p(p))
+    v, t = random_soup(3000, 2)
+    a = DeviceTree.build(v, t, 12, 7)
+    n = (a.n_nodes, a.n_recs)
+    a.release()
+    L.rt_kdtree_device_trim()                                   # frees the builder's kept work buffers
+    b = DeviceTree.build(v, t, 12, 7)
+    assert (b.n_nodes, b.n_recs) == n
+    b.release()
+    L.rt_kdtree_device_trim()
+    r.close()
