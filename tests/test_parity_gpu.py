@@ -546,3 +546,36 @@ def test_page_locked_host_block_and_builder_scratch_trim():
     b.release()
     L.rt_kdtree_device_trim()
     r.close()
+
+
+def test_resizing_the_image_and_tiling_through_the_pipe_api():
+    """rt_render_pipe_set_image_size on a live pipe (the reference's GTK resize
+    path, rt_funcs_render_pipe.c:96-109) and rt_render_pipe_set_tile."""
+    from raytracing_amd.dist import band_rows
+    sc = edge_scene("inside_box")
+    big = scenes.make_camera(96, 64, hv=0.8)
+
+    def frame(rp, cam):
+        rp.set_camera(cam)
+        rp.add_scene(sc)
+        return rp.draw()
+
+    fresh = RenderPipe(96, 64)
+    want = frame(fresh, big)
+    fresh.cleanup()
+    rp = RenderPipe(sc.w, sc.h)
+    small = frame(rp, sc.camera)
+    assert small.shape == (sc.h, sc.w, 4)
+    rp.set_image_size(96, 64)
+    assert np.array_equal(frame(rp, big), want)
+    # two halves in bands of 8 rows: each draw leaves its rows at the top of screenData
+    full = np.zeros_like(want)
+    for part in range(2):
+        rp.set_tile(8, 2, part)
+        rows = band_rows(64, 8, 2, part)
+        full[rows] = frame(rp, big)[:len(rows)]
+    assert np.array_equal(full, want)
+    rp.set_tile(16, 1, 0)
+    rp.set_image_size(sc.w, sc.h)
+    assert np.array_equal(frame(rp, sc.camera), small)
+    rp.cleanup()
