@@ -63,7 +63,7 @@
 #define RT_WAVES_CLOSEST_BIG 5
 #endif
 #ifndef RT_BIG_FRAME
-#define RT_BIG_FRAME ( 4u << 20 )
+#define RT_BIG_FRAME 4000000u
 #endif
 #ifndef RT_WAVES_SHADOW
 #define RT_WAVES_SHADOW  6   // the same for the shadow kernel (80 VGPRs)
