@@ -579,3 +579,27 @@ def test_resizing_the_image_and_tiling_through_the_pipe_api():
     rp.set_image_size(sc.w, sc.h)
     assert np.array_equal(frame(rp, sc.camera), small)
     rp.cleanup()
+
+
+def test_8k_frame_sampled_against_oracle_and_size_limits():
+    """33 Mpixel, 5 rays per pixel (87 M rays, every list longer than 2^24
+    entries): a 1-in-96 lattice against the oracle; sizes beyond the 32-bit
+    work-item range are refused, not wrapped."""
+    from raytracing_amd._lib import RtError
+    sc = scenes.sphere_scene(250, 200, 7680, 4320, reflect=0.5, stack_size=5)
+    img, ids, st, tree = hip_render(sc, 24, 12)
+    nodes, idx = tree.expand()
+    oimg, oid, _ = orc.raytrace(sc, tree.bbox, nodes, idx, x0=17, x_step=96, y0=5, y_step=96)
+    m = np.zeros(ids.shape, bool)
+    m[5::96, 17::96] = True
+    same, exact = assert_parity(img, ids, oimg, oid, m)
+    assert same == 1.0 and exact == 1.0
+    assert sc.w * sc.h <= st["raysClosest"] <= 5 * sc.w * sc.h and st["raysShadow"] == st["hits"]
+    r = HipRenderer(0)
+    with pytest.raises(RtError):
+        r.set_image(40000, 40000)                       # 1.6 G pixels
+    r.load_scene(sc, tree)
+    r.upload_lights(np.array([scenes.make_light((0.0, -50.0, 0.0), 50.0)] * 64, T.point_light))
+    with pytest.raises(RtError, match="work-item range"):
+        r.render()                                      # 33 M pixels x 64 lights >= 2^31 shadow items
+    r.close()
