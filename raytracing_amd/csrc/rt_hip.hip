@@ -475,6 +475,20 @@ struct Trav
 	uint2 n;          // node `cur`, already loaded
 };
 
+// A direction component of exactly zero (or so small that its reciprocal
+// overflows) makes the split distance (sep - origin) * inv an infinity, or a
+// NaN when the origin lies in the split plane.  A NaN compares false both
+// ways, is taken as "both children" and becomes the near child's exit distance,
+// where it rejects every hit; which cells get poisoned this way depends on the
+// whole path, including the cells behind the origin.  Such rays (the middle
+// row / column of an axis-aligned camera, mirror images of it) are therefore
+// walked exactly as the reference walks them, without the shortcuts that are
+// only equivalent for ordered distances.
+DEVI bool axis_parallel( const Ray &r )
+{
+	return __builtin_isinf( r.inv.x ) || __builtin_isinf( r.inv.y ) || __builtin_isinf( r.inv.z );
+}
+
 // start of both queries (CL/rt_funcs_primitives.cl:160-163 / :289-291): scene
 // box test; false = the ray misses the box
 template <bool STATS>
@@ -485,8 +499,9 @@ DEVI bool trav_begin( const DevScene &S, const Ray &r, Trav &t, Tally &tl )
 	// A ray that starts inside the scene box has tNear < 0; the reference walks
 	// the cells behind the origin too (its box test does not clamp).  No hit
 	// can be accepted there (t > 0 is required and a leaf only confirms hits
-	// before its own exit distance), so start at the origin instead.
-	if ( t.tNear < 0.0f )
+	// before its own exit distance), so start at the origin instead - unless the
+	// ray is parallel to an axis (see axis_parallel).
+	if ( t.tNear < 0.0f && !axis_parallel( r ) )
 		t.tNear = 0.0f;
 	t.cur = 0u;
 	t.sp = 0;
@@ -1171,9 +1186,13 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScen
 				// part of the ray beyond the light cannot contribute: walk
 				// [tNear, min(tFar, d)].  Leaves keep the same split distances, hence
 				// the same hits are counted.
-				if ( d < t.tFar )
-					t.tFar = d;
-				live = t.tNear < t.tFar;
+				live = true;
+				if ( !axis_parallel( sh ) )
+				{
+					if ( d < t.tFar )
+						t.tFar = d;
+					live = t.tNear < t.tFar;
+				}
 			}
 		}
 		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl );

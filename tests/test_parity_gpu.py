@@ -603,3 +603,36 @@ def test_8k_frame_sampled_against_oracle_and_size_limits():
     with pytest.raises(RtError, match="work-item range"):
         r.render()                                      # 33 M pixels x 64 lights >= 2^31 shadow items
     r.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3, 10, 11])
+def test_rays_parallel_to_an_axis_with_the_origin_in_a_split_plane(seed):
+    """Odd image sizes give the middle row / column a direction component of
+    exactly 0, integer geometry symmetric about the camera puts split planes
+    through the origin: the split distance 0 * inf is a NaN, which the
+    reference turns into 'both children' and into an exit distance that
+    rejects every hit.  Such rays must be walked literally (these seeds are
+    the ones a pruned walk got wrong)."""
+    rng = np.random.RandomState(seed)
+    w, h = int(rng.choice([65, 97, 33])), int(rng.choice([49, 71, 33]))
+    sc = scenes.Scene(f"axis{seed}", w, h, scenes.make_camera(w, h, hv=float(rng.choice([0.5, 0.9]))))
+    n = int(rng.choice([200, 2000]))
+    v, t = random_soup(n, seed, extent=14.0, size=3.0, center=(0.0, 0.0, 0.0))
+    for a in "xyz":
+        v["pos"][a] = np.round(v["pos"][a])
+    # box = [-17, 17]^3 or [-18, 18]^3: the middle candidate plane of the root is exactly 0 = the camera position
+    v["pos"]["x"][:2], v["pos"]["y"][:2], v["pos"]["z"][:2] = (-16, 16), (-16, 16), (-16, 16)
+    sc.meshes.append(scenes.Mesh(v, t, 0))
+    sc.flatten = lambda: (v, t)
+    for m in range(3):
+        sc.materials[m] = T.make_material((float(rng.choice([1.0, 0.5])), 0.8, 0.7, 0.6), (0, .05, .05, .05), (0, .6, .6, .6),
+                                          (10.0, .4, .4, .4), (0, .4, .4, .4), 0.02, 1.3)
+    sc.lights += [scenes.make_light((0.0, -10.0, 0.0), 40.0), scenes.make_light((5.0, 0.0, 0.0), 40.0)]
+    sc.stack_size = 6
+    depth, prims = int(rng.choice([10, 20])), int(rng.choice([2, 7]))
+    img, ids, st, tree = hip_render(sc, depth, prims)
+    nodes, idx = tree.expand()
+    assert np.frombuffer(nodes["sep"][:1].tobytes(), np.float32)[0] == 0.0
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    assert np.array_equal(ids, oid) and np.array_equal(img, oimg)
+    assert (st["raysClosest"], st["raysShadow"]) == (ost["raysClosest"], ost["raysShadow"])
