@@ -18,10 +18,22 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.RandomState(seed)
-    w, h = int(rng.choice([64, 96, 130])), int(rng.choice([48, 70, 101]))
+    w, h = int(rng.choice([64, 96, 130, 65, 33])), int(rng.choice([48, 70, 101, 49]))
     sc = scenes.Scene(f"stress{seed}", w, h, scenes.make_camera(w, h, hv=float(rng.uniform(0.3, 0.9))))
     n = int(rng.choice([1, 30, 400, 3000]))
     v, t = random_soup(n, seed, extent=float(rng.uniform(5, 30)), size=float(rng.uniform(1, 8)))
+    kind = int(rng.randint(6))
+    if kind == 1:                                   # integer coordinates: exact ties, hits on edges and vertices
+        for a in "xyz":
+            v["pos"][a] = np.round(v["pos"][a])
+    elif kind == 2 and n > 4:                       # zero-area and repeated triangles
+        t["pV1"][::3] = t["pV0"][::3]
+        t[n // 2:] = t[:n - n // 2]
+    elif kind == 3:                                 # camera inside integer geometry centred on it
+        for a in "xyz":
+            v["pos"][a] = np.round(v["pos"][a] - (60.0 if a == "z" else 0.0))
+    elif kind == 4:                                 # everything in one plane facing the camera
+        v["pos"]["z"] = 40.0
     sc.meshes.append(scenes.Mesh(v, t, 0))
     sc.flatten = lambda v=v, t=t: (v, t)        # keep the per-triangle materials 0..2
     for m in range(3):
@@ -76,6 +88,6 @@ for seed in range(first, first + count):
     r.close()
     tree.release()
     bad += not ok
-    print(f"seed {seed}: {w}x{h} tris {n} spheres {len(sc.spheres)} lights {len(sc.lights)} stack {sc.stack_size} depth {depth} leaf {prims}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"seed {seed}: kind {kind} {w}x{h} tris {n} spheres {len(sc.spheres)} lights {len(sc.lights)} stack {sc.stack_size} depth {depth} leaf {prims}: {'ok' if ok else 'MISMATCH'}", flush=True)
 print("mismatching seeds:", bad)
 sys.exit(1 if bad else 0)
