@@ -44,6 +44,8 @@ for seed in range(first, first + count):
                                           float(rng.choice([0.0, 0.02, 0.2])), float(rng.choice([1.0, 1.33, 1.6])))
     sc.spheres += [scenes.make_sphere(rng.uniform(-20, 20, 3) + (0, 0, 60), float(rng.uniform(2, 9)), int(rng.randint(3)))
                    for _ in range(int(rng.randint(0, 4)))]
+    if kind == 5:                                   # the camera sits inside a sphere (hits from the inside, side = -1)
+        sc.spheres.append(scenes.make_sphere((1.0, -2.0, 10.0), float(rng.uniform(60, 140)), int(rng.randint(3))))
     sc.lights += [scenes.make_light(rng.uniform(-40, 40, 3), float(rng.uniform(30, 120))) for _ in range(int(rng.randint(0, 4)))]
     sc.stack_size = int(rng.randint(1, 7))
     depth, prims = int(rng.choice([0, 4, 10, 20, 30])), int(rng.choice([1, 3, 7, 12, 40]))
