@@ -47,11 +47,11 @@ for seed in range(first, first + count):
     if kind == 5:                                   # the camera sits inside a sphere (hits from the inside, side = -1)
         sc.spheres.append(scenes.make_sphere((1.0, -2.0, 10.0), float(rng.uniform(60, 140)), int(rng.randint(3))))
     sc.lights += [scenes.make_light(rng.uniform(-40, 40, 3), float(rng.uniform(30, 120))) for _ in range(int(rng.randint(0, 4)))]
-    sc.stack_size = int(rng.randint(1, 7))
+    sc.stack_size = int(rng.randint(1, 9))
     depth, prims = int(rng.choice([0, 4, 10, 20, 30])), int(rng.choice([1, 3, 7, 12, 40]))
     vv, tt = sc.flatten()
-    if prims <= 3 and n >= 3000:
-        depth = min(depth, 16)      # overlapping triangles cannot be separated: references double per level
+    if n >= 3000:
+        depth = min(depth, 20 if prims > 3 else 16)      # overlapping triangles cannot be separated: references double per level
     try:
         tree = FlatTree.build(vv, tt, depth, prims)
     except Exception as e:          # tree beyond the 30-bit links: a legitimate refusal
@@ -71,7 +71,9 @@ for seed in range(first, first + count):
         same = (ids == oid).mean()
         d = np.abs(img.astype(int) - oimg.astype(int)).max()
         rays = (st["raysClosest"], st["raysShadow"]) == (ost["raysClosest"], ost["raysShadow"])
-        if same < 1.0 or d > 0 or not rays:
+        if d == 1 and same == 1.0 and rays:       # within the bar (1/255): exp / pow are the device library's, not bit-identical to libm
+            print(f"seed {seed} overlap {overlap}: one 8-bit step apart on {(np.abs(img.astype(int) - oimg.astype(int)).max(-1) > 0).sum()} pixels", flush=True)
+        if same < 1.0 or d > 1 or not rays:
             ok = False
             print(f"seed {seed} overlap {overlap}: ids {same:.5f} maxdiff {d} rays {rays} ({st['raysClosest']},{st['raysShadow']}) vs ({ost['raysClosest']},{ost['raysShadow']})", flush=True)
     parts = int(rng.choice([2, 3, 5]))
