@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,11 +110,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL ("nccl") needs one GPU per rank; RT_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU
+        backend = os.environ.get("RT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     sc = wl["make"]()
@@ -129,7 +139,7 @@ def main():
     dtree.release()
 
     stream = torch.cuda.current_stream()
-    r = HipRenderer(local_rank, stream=stream.cuda_stream)
+    r = HipRenderer(local_dev, stream=stream.cuda_stream)
     r.load_scene(sc, tree)
     r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
     r.set_tile(rdist.BAND_H, world, rank)
@@ -137,10 +147,18 @@ def main():
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world)
     frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
 
+    dbg = bool(os.environ.get("RT_BENCH_WATCHDOG"))
+
     def step(flags=0):
         r.render(flags, d_out=frame_local.data_ptr())
+        if dbg:
+            r.sync()
+            print(f"[rank {rank}] frame rendered", file=sys.stderr, flush=True)
         if world > 1:
-            return rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
+            out = rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
+            if dbg:
+                print(f"[rank {rank}] frame gathered", file=sys.stderr, flush=True)
+            return out
         return frame_local
 
     def fence():

@@ -73,6 +73,10 @@ def gather_frame(local, h, w, band_h=BAND_H, dst=0, group=None):
     elif local.shape[0] > pad:
         local = local[:pad]
     local = local.contiguous()
+    # gloo (CPU rehearsals of the multi-rank path) cannot gather device tensors: stage through the host
+    device = local.device
+    if device.type != "cpu" and dist.get_backend(group) == "gloo":
+        local = local.cpu()
     # all-to-one: every source uses its own direct link to dst
     bufs = None
     if rank == dst:
@@ -86,6 +90,8 @@ def gather_frame(local, h, w, band_h=BAND_H, dst=0, group=None):
     if rank != dst:
         return None
     nb = pad // band_h
+    if big.device != device:
+        big = big.to(device)
     return big.view(world, nb, band_h, w, 4).permute(1, 0, 2, 3, 4).reshape(nb * world * band_h, w, 4)[:h]
 
 
