@@ -1514,10 +1514,12 @@ rt_hip_ctx *rt_hip_create( int device )
 	// a streaming pass gains nothing from more than a few waves per SIMD
 	if ( c->gridLight > RT_STREAM_OCC * c->numCU ) c->gridLight = RT_STREAM_OCC * c->numCU;
 
-	int prLow = 0, prHigh = 0;
-	bool ok = hipDeviceGetStreamPriorityRange( &prLow, &prHigh ) == hipSuccess;
+	// Ordinary priority: low-priority auxiliary streams bought nothing once their grids were
+	// limited, and when two processes shared one GPU their queues were starved for good
+	// (a frame never completed in about one run out of three).
+	bool ok = true;
 	for ( auto &a : c->aux )
-		ok = ok && hipStreamCreateWithPriority( &a, hipStreamNonBlocking, prLow ) == hipSuccess;
+		ok = ok && hipStreamCreateWithFlags( &a, hipStreamNonBlocking ) == hipSuccess;
 	for ( int k = 0; k < RT_MAX_SLOTS && ok; ++k )
 		ok = hipEventCreateWithFlags( &c->evHit[k], hipEventDisableTiming ) == hipSuccess
 			&& hipEventCreateWithFlags( &c->evLit[k], hipEventDisableTiming ) == hipSuccess;

@@ -16,8 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_bench(n, port):
     env = dict(os.environ, RT_DIST_BACKEND="gloo", RT_BENCH_WATCHDOG="150", PYTHONPATH=ROOT)
-    # two processes on one device: the in-order schedule (the overlapped one was seen to stall
-    # intermittently when processes SHARE a GPU, which the benchmark itself never does)
+    # two processes share one device here: the in-order schedule keeps the number of busy queues small
     args = ["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "config2", "--depth", "20", "--no-cpu-baseline", "--no-overlap"]
     if n == 1:
         cmd = [sys.executable, "bench.py"] + args
