@@ -22,6 +22,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# A frame runs on three streams of its own (closest-hit chain + two auxiliary ones); with the
+# collective library's streams on top a rank would exceed the runtime's default of four
+# hardware queues per process and two of them would be folded into one queue, which
+# serialises what is meant to overlap.  Must be set before the HIP runtime starts.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
