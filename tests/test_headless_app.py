@@ -79,3 +79,29 @@ def test_headless_app_renders_the_demo_scene_and_resumes(tmp_path):
     assert n2 == 3 and t2 == np.float32(np.float32(dt) + np.float32(dt))
     png = read_png(tmp_path / "pngs" / "2.png")
     assert png.shape == (h, w, 3) and png.any()
+
+
+@pytest.mark.gpu
+def test_headless_app_adds_an_obj_mesh(tmp_path):
+    """--obj: rt_mesh_load_from_obj + rt_mesh_add on top of the demo scene."""
+    from oracle import obj_cases as oc
+    oc.write_case(str(tmp_path))
+    # put the little mesh where the demo camera sees it: scaled up, above the water in front of the big sphere
+    text = open(tmp_path / "case.obj").read().splitlines()
+    moved = []
+    for line in text:
+        if line.startswith("v "):
+            x, y, z = (float(s) for s in line.split()[1:4])
+            line = f"v {8 * x - 12:.3f} {8 * y - 8:.3f} {8 * z + 5:.3f}"
+        moved.append(line)
+    (tmp_path / "big.obj").write_text("\n".join(moved) + "\n")
+    run = lambda *a: subprocess.run([APP, "--size", "256x160", "--squares", "30", "--frames", "1", "--format", "ppm", *a],
+                                    cwd=tmp_path, check=True, capture_output=True, text=True, timeout=120)
+    a = run("--out", "plain")
+    b = run("--out", "withobj", "--obj", "big.obj")
+    assert "1810 triangles" in a.stdout and "1817 triangles" in b.stdout, (a.stdout, b.stdout)
+    fa, fb = read_ppm(tmp_path / "plain" / "0.ppm"), read_ppm(tmp_path / "withobj" / "0.ppm")
+    changed = (fa != fb).any(axis=-1).mean()
+    assert 0.001 < changed < 0.5, changed
+    c = run("--out", "missing", "--obj", "absent.obj")          # unreadable file: message, scene without it
+    assert "obj load error" in c.stderr and np.array_equal(read_ppm(tmp_path / "missing" / "0.ppm"), fa)
