@@ -81,12 +81,20 @@ def scene_box(verts):
     return bb
 
 
-def kdtree_build(verts, tris):
+def kdtree_build(verts, tris, builder=None):
     """The reference's rt_kdtree_make_childs + rt_kdtree_pack_to_buffer on host
     arrays, driven exactly like rt_kdtree_build drives them (:1139-1198).
     Depth and leaf size are the reference's compile-time 10 and 7.
+    `builder`: another library exporting the same two functions (the product's
+    reference-signature builder), driven the same way; the scene box always
+    comes from the reference.
     -> (bbox, nodes T.cl_kdtree_node[], idx uint64[])"""
-    L = lib()
+    lib()
+    L = builder if builder is not None else lib()
+    L.rt_kdtree_make_childs.restype = CountInfo
+    L.rt_kdtree_make_childs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(KdNode), C.c_void_p, C.c_int]
+    L.rt_kdtree_pack_to_buffer.restype = CountInfo
+    L.rt_kdtree_pack_to_buffer.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(KdNode), C.c_uint64, C.c_uint64]
     verts = np.ascontiguousarray(verts, T.vertex)
     tris = np.ascontiguousarray(tris, T.triangle)
     n = len(tris)
