@@ -77,15 +77,138 @@ __device__ inline void tri_extent( float a, float b, float c, float &mn, float &
 	if ( mn > c ) mn = c;
 }
 
-__global__ __launch_bounds__( TB ) void k_extents( const rt_vertex *verts, const rt_triangle *tris, uint32_t nT, float *ext )
+// what the host learns about the geometry before the first level
+struct GeomInfo
+{
+	uint32_t badIndex;     // some triangle names a vertex that does not exist
+	uint32_t maxMat;       // highest material slot (saturated to 32 bits)
+	float box[6];          // scene box: centre xyz, half extent xyz
+};
+
+// Extents of every triangle; the index check and the highest material slot ride
+// along (the triangles are read here anyway). A triangle with a bad index gets
+// no extents and raises the flag: the host gives up before anything else reads it.
+__global__ __launch_bounds__( TB ) void k_extents( const rt_vertex *verts, const rt_triangle *tris, uint32_t nT, uint64_t nV, float *ext,
+	GeomInfo *info )
 {
 	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i >= nT )
+	uint32_t m = 0;
+	if ( i < nT )
+	{
+		const rt_triangle t = tris[i];
+		m = t.mat > 0xffffffffull ? 0xffffffffu : (uint32_t) t.mat;
+		if ( t.pV0 >= nV || t.pV1 >= nV || t.pV2 >= nV )
+			info->badIndex = 1u;
+		else
+		{
+			const rt_vector3 p0 = verts[t.pV0].pos, p1 = verts[t.pV1].pos, p2 = verts[t.pV2].pos;
+			tri_extent( p0.x, p1.x, p2.x, ext[i], ext[3ull * nT + i] );
+			tri_extent( p0.y, p1.y, p2.y, ext[(size_t) nT + i], ext[4ull * nT + i] );
+			tri_extent( p0.z, p1.z, p2.z, ext[2ull * nT + i], ext[5ull * nT + i] );
+		}
+	}
+	for ( int off = 32; off; off >>= 1 )
+	{
+		const uint32_t o = (uint32_t) __shfl_xor( (int) m, off );
+		m = m > o ? m : o;
+	}
+	if ( ( threadIdx.x & 63 ) == 0 && m )
+		atomicMax( &info->maxMat, m );
+}
+
+// ---- scene box, rt_funcs_render_pipe.c:1114-1137 -------------------------
+// The reference walks the vertices with "mn > p ? p : mn" starting from vertex 0:
+// a NaN coordinate never replaces a number, and a NaN in vertex 0 stays for good.
+// Minimum and maximum do not depend on the order otherwise (the two zeros differ
+// in sign only, and the margin of 1 added afterwards hides that).
+constexpr int BOX_BLOCKS = 1024;
+
+__global__ __launch_bounds__( TB ) void k_box_partial( const rt_vertex *verts, uint64_t nV, float *part )
+{
+	const float inf = __builtin_huge_valf();
+	float mn[3] = { inf, inf, inf }, mx[3] = { -inf, -inf, -inf };
+	for ( uint64_t i = (uint64_t) blockIdx.x * TB + threadIdx.x; i < nV; i += (uint64_t) gridDim.x * TB )
+	{
+		const rt_vector3 p = verts[i].pos;
+		const float c[3] = { p.x, p.y, p.z };
+		for ( int a = 0; a < 3; ++a )
+		{
+			if ( c[a] < mn[a] ) mn[a] = c[a];
+			if ( c[a] > mx[a] ) mx[a] = c[a];
+		}
+	}
+	__shared__ float red[6][TB / 64];
+	for ( int a = 0; a < 3; ++a )
+	{
+		for ( int off = 32; off; off >>= 1 )
+		{
+			const float o = __shfl_xor( mn[a], off ), q = __shfl_xor( mx[a], off );
+			if ( o < mn[a] ) mn[a] = o;
+			if ( q > mx[a] ) mx[a] = q;
+		}
+		if ( ( threadIdx.x & 63 ) == 0 )
+		{
+			red[a][threadIdx.x >> 6] = mn[a];
+			red[3 + a][threadIdx.x >> 6] = mx[a];
+		}
+	}
+	__syncthreads();
+	if ( threadIdx.x < 6 )
+	{
+		float v = red[threadIdx.x][0];
+		for ( int w = 1; w < TB / 64; ++w )
+		{
+			const float o = red[threadIdx.x][w];
+			if ( threadIdx.x < 3 ? o < v : o > v ) v = o;
+		}
+		part[6 * blockIdx.x + threadIdx.x] = v;
+	}
+}
+
+// one wave: folds the partial boxes, applies the rules for vertex 0 and the
+// margin, and fills the root's entry of the level table
+__global__ __launch_bounds__( 64 ) void k_box_final( const rt_vertex *verts, uint64_t nV, const float *part, int nPart, uint32_t nT,
+	GeomInfo *info, float *rootBox, uint32_t *rootStart, uint32_t *rootCount )
+{
+	const float inf = __builtin_huge_valf();
+	float mn[3] = { inf, inf, inf }, mx[3] = { -inf, -inf, -inf };
+	for ( int b = threadIdx.x; b < nPart; b += 64 )
+		for ( int a = 0; a < 3; ++a )
+		{
+			const float o = part[6 * b + a], q = part[6 * b + 3 + a];
+			if ( o < mn[a] ) mn[a] = o;
+			if ( q > mx[a] ) mx[a] = q;
+		}
+	for ( int a = 0; a < 3; ++a )
+		for ( int off = 32; off; off >>= 1 )
+		{
+			const float o = __shfl_xor( mn[a], off ), q = __shfl_xor( mx[a], off );
+			if ( o < mn[a] ) mn[a] = o;
+			if ( q > mx[a] ) mx[a] = q;
+		}
+	if ( threadIdx.x != 0 )
 		return;
-	const rt_vector3 p0 = verts[tris[i].pV0].pos, p1 = verts[tris[i].pV1].pos, p2 = verts[tris[i].pV2].pos;
-	tri_extent( p0.x, p1.x, p2.x, ext[i], ext[3ull * nT + i] );
-	tri_extent( p0.y, p1.y, p2.y, ext[(size_t) nT + i], ext[4ull * nT + i] );
-	tri_extent( p0.z, p1.z, p2.z, ext[2ull * nT + i], ext[5ull * nT + i] );
+	float first[3] = { 0.0f, 0.0f, 0.0f };
+	if ( nV )
+	{
+		const rt_vector3 p = verts[0].pos;
+		first[0] = p.x; first[1] = p.y; first[2] = p.z;
+	}
+	for ( int a = 0; a < 3; ++a )
+	{
+		float lo = mn[a], hi = mx[a];
+		if ( nV == 0 ) lo = hi = 0.0f;
+		else if ( first[a] != first[a] ) lo = hi = first[a];
+		lo -= 1.0f;
+		hi += 1.0f;
+		const float c = ( lo + hi ) * 0.5f, e = ( hi - lo ) * 0.5f;
+		info->box[a] = c;
+		info->box[3 + a] = e;
+		rootBox[a] = c;
+		rootBox[3 + a] = e;
+	}
+	*rootStart = 0u;
+	*rootCount = nT;
 }
 
 __global__ __launch_bounds__( TB ) void k_iota( uint32_t *refs, uint32_t *refNode, uint32_t n )
@@ -473,38 +596,13 @@ __global__ __launch_bounds__( TB ) void k_shade_records( const rt_vertex *verts,
 
 inline unsigned grid_of( size_t n ) { return (unsigned) ( ( n + TB - 1 ) / TB ); }
 
-// scene box on the host, :1114-1137 (the vertices are host data)
-void scene_box( const rt_vertex *verts, uint64_t n, rt_box &bbox )
-{
-	float mnx = 0, mny = 0, mnz = 0, mxx = 0, mxy = 0, mxz = 0;
-	for ( uint64_t i = 0; i < n; ++i )
-	{
-		const rt_vector3 &p = verts[i].pos;
-		mnx = ( mnx > p.x || i == 0 ) ? p.x : mnx;
-		mny = ( mny > p.y || i == 0 ) ? p.y : mny;
-		mnz = ( mnz > p.z || i == 0 ) ? p.z : mnz;
-		mxx = ( mxx < p.x || i == 0 ) ? p.x : mxx;
-		mxy = ( mxy < p.y || i == 0 ) ? p.y : mxy;
-		mxz = ( mxz < p.z || i == 0 ) ? p.z : mxz;
-	}
-	mnx -= 1.0f; mny -= 1.0f; mnz -= 1.0f;
-	mxx += 1.0f; mxy += 1.0f; mxz += 1.0f;
-	memset( &bbox, 0, sizeof( bbox ) );
-	bbox.center.x = ( mnx + mxx ) * 0.5f;
-	bbox.center.y = ( mny + mxy ) * 0.5f;
-	bbox.center.z = ( mnz + mxz ) * 0.5f;
-	bbox.extents.x = ( mxx - mnx ) * 0.5f;
-	bbox.extents.y = ( mxy - mny ) * 0.5f;
-	bbox.extents.z = ( mxz - mnz ) * 0.5f;
-}
-
 struct Scratch
 {
-	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, scan, cub, info, leafPool, work, sub, order;
+	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, scan, cub, info, leafPool, work, sub, order, geom;
 	uint32_t *hTotals = nullptr;
 	void release()
 	{
-		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &scan, &cub, &info, &leafPool, &work, &sub, &order } )
+		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &scan, &cub, &info, &leafPool, &work, &sub, &order, &geom } )
 			v->release();
 		if ( hTotals ) (void) hipHostFree( hTotals );
 		hTotals = nullptr;
@@ -590,18 +688,9 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 		return 1;
 	if ( trianglesCount >= ( 1ull << 30 ) || maxDepth < 0 || maxDepth > RT_HIP_MAX_TREE_DEPTH || maxPrims < 1 )
 		return 2;
-	uint32_t maxMat = 0;
-	for ( uint64_t i = 0; i < trianglesCount; ++i )
-	{
-		if ( tris[i].pV0 >= vertexCount || tris[i].pV1 >= vertexCount || tris[i].pV2 >= vertexCount )
-			return 3;
-		if ( tris[i].mat > maxMat ) maxMat = (uint32_t) tris[i].mat;
-	}
 	memset( out, 0, sizeof( *out ) );
 	hipStream_t s = (hipStream_t) hipStream;
 	const uint32_t nT = (uint32_t) trianglesCount;
-	scene_box( verts, vertexCount, out->bbox );
-	out->maxMaterial = maxMat;
 
 	// Work buffers are kept between builds of one thread on one device (a frame
 	// loop rebuilds a tree of about the same size every frame; allocating and
@@ -614,14 +703,25 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 		g_scratchDev = dev;
 	}
 	Scratch &S = g_scratch;
+	if ( !S.hTotals )
+		GCHK( hipHostMalloc( (void **) &S.hTotals, 4 * sizeof( uint32_t ) + sizeof( GeomInfo ), hipHostMallocDefault ) );
+	uint32_t *hTotals = S.hTotals;
+	GeomInfo *hGeom = (GeomInfo *) ( S.hTotals + 4 );
 
-	// inputs
+	// inputs; the index check, the highest material slot and the scene box are
+	// taken from the device copy (a host pass over 1 M triangles and their
+	// vertices costs 2 ms, more than a quarter of the whole build)
 	if ( int rc = S.verts.reserve( sizeof( rt_vertex ) * ( vertexCount ? vertexCount : 1 ), s ) ) return rc;
 	if ( int rc = S.tris.reserve( sizeof( rt_triangle ) * ( nT ? nT : 1 ), s ) ) return rc;
 	if ( vertexCount ) GCHK( hipMemcpyAsync( S.verts.p, verts, sizeof( rt_vertex ) * vertexCount, hipMemcpyHostToDevice, s ) );
 	if ( nT ) GCHK( hipMemcpyAsync( S.tris.p, tris, sizeof( rt_triangle ) * nT, hipMemcpyHostToDevice, s ) );
 	if ( int rc = S.ext.reserve( 6 * sizeof( float ) * ( nT ? nT : 1 ), s ) ) return rc;
-	if ( nT ) hipLaunchKernelGGL( k_extents, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT, S.ext.as<float>() );
+	if ( int rc = S.geom.reserve( sizeof( GeomInfo ) + 6 * sizeof( float ) * BOX_BLOCKS, s ) ) return rc;
+	GeomInfo *dGeom = S.geom.as<GeomInfo>();
+	float *boxPart = (float *) ( dGeom + 1 );
+	GCHK( hipMemsetAsync( dGeom, 0, sizeof( GeomInfo ), s ) );
+	if ( nT ) hipLaunchKernelGGL( k_extents, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
+		vertexCount, S.ext.as<float>(), dGeom );
 
 	// level 0: the root holds every triangle in index order
 	DVec *refsCur = &S.refsA, *refsNext = &S.refsB, *tabCur = &S.nodeA, *tabNext = &S.nodeB;
@@ -632,18 +732,19 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 	LevelTab cur;
 	if ( int rc = level_tab( *tabCur, 1, s, cur ) ) return rc;
 	{
-		const float rootBox[6] = { out->bbox.center.x, out->bbox.center.y, out->bbox.center.z,
-			out->bbox.extents.x, out->bbox.extents.y, out->bbox.extents.z };
-		const uint32_t se[2] = { 0u, nT };
-		GCHK( hipMemcpyAsync( cur.box, rootBox, sizeof( rootBox ), hipMemcpyHostToDevice, s ) );
-		GCHK( hipMemcpyAsync( cur.start, &se[0], 4, hipMemcpyHostToDevice, s ) );
-		GCHK( hipMemcpyAsync( cur.count, &se[1], 4, hipMemcpyHostToDevice, s ) );
+		const uint64_t want = ( vertexCount + TB - 1 ) / TB;
+		const int nPart = (int) ( want < 1 ? 1 : want > (uint64_t) BOX_BLOCKS ? (uint64_t) BOX_BLOCKS : want );
+		hipLaunchKernelGGL( k_box_partial, dim3( nPart ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), vertexCount, boxPart );
+		hipLaunchKernelGGL( k_box_final, dim3( 1 ), dim3( 64 ), 0, s, S.verts.as<rt_vertex>(), vertexCount, boxPart, nPart, nT, dGeom,
+			cur.box, cur.start, cur.count );
+		GCHK( hipMemcpyAsync( hGeom, dGeom, sizeof( GeomInfo ), hipMemcpyDeviceToHost, s ) );
 		GCHK( hipStreamSynchronize( s ) );
+		if ( hGeom->badIndex )
+			return 3;
+		out->maxMaterial = hGeom->maxMat;
+		out->bbox.center.x = hGeom->box[0]; out->bbox.center.y = hGeom->box[1]; out->bbox.center.z = hGeom->box[2];
+		out->bbox.extents.x = hGeom->box[3]; out->bbox.extents.y = hGeom->box[4]; out->bbox.extents.z = hGeom->box[5];
 	}
-
-	if ( !S.hTotals )
-		GCHK( hipHostMalloc( (void **) &S.hTotals, 3 * sizeof( uint32_t ), hipHostMallocDefault ) );
-	uint32_t *hTotals = S.hTotals;
 
 	std::vector<uint32_t> levelFirst, levelCount;
 	uint64_t nodesTotal = 0, leafRefs = 0;

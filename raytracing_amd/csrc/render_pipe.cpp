@@ -18,11 +18,80 @@
 char *rt_cl_include_path = nullptr;
 char *rt_cl_raytrace_kernel_path = nullptr;
 
+// Growing array for the geometry handed to the tree builder. From 1 MiB up it
+// lives in page-locked memory where the driver provides it: the GPU builder's
+// upload of 1 M triangles then runs at the bus rate instead of through a
+// staging copy. clear() keeps the block, so a frame loop allocates once.
+template <class T> struct GeomBuf
+{
+	static constexpr size_t PIN_FROM = 1u << 20;
+	rt_hip_ctx *hip = nullptr;
+	T *p = nullptr;
+	size_t n = 0, cap = 0;
+	bool pinned = false;
+
+	T *data() { return p; }
+	size_t size() const { return n; }
+	void clear() { n = 0; }
+	void reserve( size_t want )
+	{
+		if ( want <= cap )
+			return;
+		size_t c = cap ? cap * 2 : 64;
+		if ( c < want ) c = want;
+		T *q = nullptr;
+		bool qPinned = false;
+		if ( hip && c * sizeof( T ) >= PIN_FROM )
+		{
+			q = (T *) rt_hip_alloc_host( hip, c * sizeof( T ) );
+			qPinned = q != nullptr;
+		}
+		if ( !q )
+			q = (T *) malloc( c * sizeof( T ) );
+		if ( !q )
+		{
+			fprintf( stderr, "rt: out of memory (%zu bytes of geometry)\n", c * sizeof( T ) );
+			exit( -3 );
+		}
+		if ( n )
+			memcpy( q, p, n * sizeof( T ) );
+		drop();
+		p = q;
+		cap = c;
+		pinned = qPinned;
+	}
+	void append( const T *src, size_t k )
+	{
+		if ( !k )
+			return;
+		reserve( n + k );
+		memcpy( p + n, src, k * sizeof( T ) );
+		n += k;
+	}
+	T *grow( size_t k )      // k uninitialised entries at the end
+	{
+		reserve( n + k );
+		T *at = p + n;
+		n += k;
+		return at;
+	}
+	void drop()
+	{
+		if ( pinned )
+			rt_hip_free_host( hip, p );
+		else
+			free( p );
+		p = nullptr;
+		cap = 0;
+	}
+	void release() { drop(); n = 0; }
+};
+
 struct rt_pipe_impl
 {
 	rt_hip_ctx *hip = nullptr;
-	std::vector<rt_vertex> verts;
-	std::vector<rt_triangle> tris;
+	GeomBuf<rt_vertex> verts;
+	GeomBuf<rt_triangle> tris;
 	std::vector<rt_sphere> spheres;
 	std::vector<rt_point_light> lights;
 	std::vector<rt_material> mats;
@@ -126,6 +195,7 @@ void rt_render_pipe_create( rt_render_pipe *pRp, int w, int h )
 	pRp->impl->hip = rt_hip_create( g_device );
 	if ( !pRp->impl->hip )
 		die_hip( "cannot create the HIP context" );
+	pRp->impl->verts.hip = pRp->impl->tris.hip = pRp->impl->hip;
 	rt_init_buffers( pRp );
 	{
 		rt_camera &c = pRp->impl->cam;
@@ -231,17 +301,15 @@ void rt_render_pipe_add_triangles( rt_render_pipe *pRp, rt_vertex *pV, rt_triang
 		grow_blocks( &pRp->vertexBlocks, VERTEX_IN_BLOCK * sizeof( rt_vertex ), sizeof( rt_vertex ) * vCount );
 
 	const rt_ulong base = pRp->vertexCount;
-	im->verts.insert( im->verts.end(), pV + vOffset, pV + vOffset + vCount );
-	im->tris.reserve( im->tris.size() + tCount );
+	im->verts.append( pV + vOffset, vCount );
+	rt_triangle *dst = im->tris.grow( tCount );
 	for ( rt_ulong i = 0; i < tCount; ++i )
 	{
 		const rt_triangle &s = pTr[i + tOffset];
-		rt_triangle t;
-		t.pV0 = base + s.pV0 - vOffset;
-		t.pV1 = base + s.pV1 - vOffset;
-		t.pV2 = base + s.pV2 - vOffset;
-		t.mat = tGroup;
-		im->tris.push_back( t );
+		dst[i].pV0 = base + s.pV0 - vOffset;
+		dst[i].pV1 = base + s.pV1 - vOffset;
+		dst[i].pV2 = base + s.pV2 - vOffset;
+		dst[i].mat = tGroup;
 	}
 	pRp->trianglesCount += tCount;
 	pRp->vertexCount += vCount;
@@ -456,6 +524,8 @@ void rt_render_pipe_cleanup( rt_render_pipe *pRp )
 	pRp->screenData = NULL;
 	if ( pRp->impl )
 	{
+		pRp->impl->verts.release();
+		pRp->impl->tris.release();
 		rt_hip_destroy( pRp->impl->hip );
 		delete pRp->impl;
 		pRp->impl = nullptr;
