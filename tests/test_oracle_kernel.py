@@ -14,6 +14,7 @@ from oracle import orc
 from oracle.gen_golden import image_scenes
 from raytracing_amd import scenes
 from raytracing_amd import types as T
+from tests import known_answers
 from tests.helpers import GOLD, geom_hash
 
 IMG = image_scenes()
@@ -75,6 +76,47 @@ def test_single_triangle_shading_known_answer():
     assert img[cy, cx, :3].tolist() == [int(f32(255.0) * min(e, f32(1.0))) for e in exp]
     assert img[cy, cx, 3] == 0
     assert (hit == -1).any() and img[hit == -1].max() == 0      # misses are black
+
+
+@pytest.mark.parametrize("case", sorted(known_answers.all_cases()))
+@pytest.mark.parametrize("depth,prims", [(10, 7), (10, 1)])
+def test_hand_derived_shading_cases(case, depth, prims):
+    """Shadow sums (partial, summed, clamped, beyond the light), the specular
+    term, a mirror, a refraction with the shadow cast through the refracting
+    surface, and both child rays with their fold order: centre-pixel colours
+    worked out from the reference's formulas in tests/known_answers.py."""
+    sc, want = known_answers.expected(case, prims)
+    v, t = sc.flatten()
+    img, hit, _ = orc.raytrace(sc, *orc.kdtree_build(v, t, depth, prims), threads=1)
+    assert hit[known_answers.CENTRE, known_answers.CENTRE] == 0
+    assert img[known_answers.CENTRE, known_answers.CENTRE].tolist() == want
+
+
+@pytest.mark.parametrize("kind", ["mirror", "refraction"])
+def test_hand_derived_oblique_child_rays(kind):
+    """Mirror and Snell directions at oblique incidence: the child ray must
+    find a small target placed along the direction worked out in double
+    precision, and the folded colour must match within one 8-bit step."""
+    sc, want, _ = known_answers.oblique_case(kind)
+    v, t = sc.flatten()
+    img, hit, st = orc.raytrace(sc, *orc.kdtree_build(v, t), threads=1)
+    c = known_answers.CENTRE
+    assert hit[c, c] == 0
+    assert np.abs(img[c, c].astype(int) - np.array(want)).max() <= 1
+    # and the target matters: without it the pixel is visibly darker
+    sc.meshes.pop()
+    v, t = sc.flatten()
+    bare, _, _ = orc.raytrace(sc, *orc.kdtree_build(v, t), threads=1)
+    assert (img[c, c, :3].astype(int) - bare[c, c, :3].astype(int)).min() >= 5
+
+
+def test_hand_derived_refraction_falloff_within_one_step():
+    """exp() of the fold weight is the platform's: one 8-bit step of slack."""
+    sc, want = known_answers.refraction_case(falloff=0.05)
+    v, t = sc.flatten()
+    img, _, _ = orc.raytrace(sc, *orc.kdtree_build(v, t), threads=1)
+    got = img[known_answers.CENTRE, known_answers.CENTRE].astype(int)
+    assert np.abs(got - np.array(want)).max() <= 1
 
 
 @pytest.mark.parametrize("name", sorted(IMG))

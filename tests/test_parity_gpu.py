@@ -16,6 +16,7 @@ from raytracing_amd import scenes
 from raytracing_amd import types as T
 from raytracing_amd.pipe import (RT_HIP_HITIDS, RT_HIP_STATS, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
                                  RT_PARAM_STACK_SIZE, RT_PARAM_TREE_CACHE, FlatTree, HipRenderer, RenderPipe)
+from tests import known_answers
 from tests.helpers import GOLD, random_soup
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +45,40 @@ def assert_parity(img, ids, oimg, oid, mask=None):
     d = np.abs(img.astype(int) - oimg.astype(int))[mask]
     assert d.max() <= 1, f"rgb differs by {d.max()}"
     return same, (d.max(axis=-1) == 0).mean()
+
+
+@pytest.mark.parametrize("case", sorted(known_answers.all_cases()))
+@pytest.mark.parametrize("depth,prims", [(10, 7), (10, 1)])
+def test_hand_derived_shading_cases_on_the_gpu(case, depth, prims):
+    """Centre-pixel colours worked out by hand from the reference's formulas
+    (tests/known_answers.py), compared with the HIP path directly - no oracle
+    in between - and then the whole frame with the oracle."""
+    sc, want = known_answers.expected(case, prims)
+    img, ids, _, tree = hip_render(sc, depth, prims)
+    c = known_answers.CENTRE
+    assert ids[c, c] == 0 and img[c, c].tolist() == want
+    nodes, idx = tree.expand()
+    oimg, oid, _ = orc.raytrace(sc, tree.bbox, nodes, idx, threads=2)
+    assert np.array_equal(ids, oid) and np.array_equal(img, oimg)
+    tree.release()
+
+
+@pytest.mark.parametrize("kind", ["mirror", "refraction"])
+def test_hand_derived_oblique_child_rays_on_the_gpu(kind):
+    sc, want, _ = known_answers.oblique_case(kind)
+    img, ids, _, tree = hip_render(sc)
+    tree.release()
+    c = known_answers.CENTRE
+    assert ids[c, c] == 0
+    assert np.abs(img[c, c].astype(int) - np.array(want)).max() <= 1     # expectation worked out in double precision
+
+
+def test_hand_derived_refraction_falloff_on_the_gpu():
+    sc, want = known_answers.refraction_case(falloff=0.05)
+    img, _, _, tree = hip_render(sc)
+    tree.release()
+    c = known_answers.CENTRE
+    assert np.abs(img[c, c].astype(int) - np.array(want)).max() <= 1     # exp() is the device library's
 
 
 @pytest.mark.parametrize("name", sorted(IMG))
