@@ -216,8 +216,41 @@ def oblique_case(kind):
     return sc, [int(255.0 * v) for v in out] + [0], q
 
 
+def sphere_case(kind):
+    """The receiver is a sphere of radius 10 about (0,0,30): the centre ray
+    meets it at P = (0,0,20), t = 20 exactly, normal (P - c)/r = (0,0,-1)
+    (:42-46), so the numbers are those of the triangle receiver.  A unit sphere
+    of opacity 0.3 sits on the shadow ray.  The shadow query adds the spheres'
+    opacities (:418-448), clamps, and then the triangles' - but the triangle
+    query returns before resetting its sum when the shadow ray misses the scene
+    box (:289-293), so the sphere sum is counted a second time."""
+    sc = _scene("ka_sphere_" + kind, (0.0, -10.0, 10.0))
+    sc.materials[0] = T.make_material(COL_A, (0.0, AMB, AMB, AMB), (0.0, DIF, DIF, DIF), (1.0, 0, 0, 0), (0, 0, 0, 0), 0.0, 1.0)
+    sc.materials[1] = _plain((0.3, 0, 0, 0))
+    sc.materials[2] = _plain((1.0, 0, 0, 0))
+    sc.spheres.append(scenes.make_sphere((0.0, 0.0, 30.0), 10.0, 0))
+    if kind == "lit":
+        shadowed = 0.0
+    else:
+        sc.spheres.append(scenes.make_sphere((0.0, -5.0, 15.0), 1.0, 1))
+        shadowed = 0.3
+    if kind == "blocker_counted_twice":
+        # the only triangle is far to the side: every ray of the centre pixel misses the scene box
+        _tri(sc, [(50, 0, 20), (52, 0, 20), (51, 2, 20)], (0, 0, -1), 2)
+        shadowed = float(f32(0.3) + f32(0.3))
+    else:
+        # two walls left and right put the whole shadow ray inside the scene box without touching it
+        _tri(sc, [(-6, -20, 0), (-6, 20, 0), (-6, 0, 40)], (1, 0, 0), 2)
+        _tri(sc, [(6, -20, 0), (6, 20, 0), (6, 0, 40)], (-1, 0, 0), 2)
+    d = np.sqrt(f32(200.0))
+    n_dot_l = f32(-1.0) * (f32(-10.0) / d)
+    return sc, to_bytes(lit(BGR_A, n_dot_l, 10.0, d, shadowed))
+
+
 def all_cases():
     cases = {}
+    for k in ("lit", "blocker_in_the_box", "blocker_counted_twice"):
+        cases["sphere_" + k] = sphere_case(k)
     for k in ("none", "opaque", "half", "two_quarters", "three_halves_clamp", "beyond_the_light"):
         cases["shadow_" + k] = shadow_case(k)
     cases["specular"] = specular_case()
