@@ -247,6 +247,31 @@ def sphere_case(kind):
     return sc, to_bytes(lit(BGR_A, n_dot_l, 10.0, d, shadowed))
 
 
+def camera_case(w=48, h=32):
+    """Ray generation, CL/rt_raytrace.cl:27-28,60-79: pixel (x, y) looks along
+    (ndc_x * P11, ndc_y * P22, 1) with ndc = 2 * pixel / (size - 1) - 1, taken
+    through the camera's world matrix as a ROW vector (CL/rt_funcs_math.cl:126-147:
+    rows 1-3 are the images of the view axes, row 4 the position).  The world
+    matrix here turns view +z into world +x and view +x into world -z and moves
+    the eye to (5,-3,2).  One small target per chosen pixel sits 20 units down
+    its ray; the pixel pitch there is 0.5, the targets are 0.2 wide.
+    -> (scene, {(x, y): triangle id})"""
+    world = np.array([[0, 0, -1, 0], [0, 1, 0, 0], [1, 0, 0, 0], [5, -3, 2, 1]], np.float32)
+    sc = scenes.Scene("ka_camera", w, h, scenes.make_camera(w, h, world=world))
+    sc.materials[0] = _plain((1.0, 0, 0, 0))
+    p11 = 2.0 * np.tan(0.125 * np.pi / 2.0) * (w / h)
+    p22 = 2.0 * np.tan(0.125 * np.pi / 2.0)
+    want = {}
+    for k, (x, y) in enumerate([(0, 0), (w - 1, h - 1), (0, h - 1), (w - 1, 0), (5, 20), (w // 2, h // 2), (w - 2, 1)]):
+        vx = (2.0 * x / (w - 1) - 1.0) * p11
+        vy = (2.0 * y / (h - 1) - 1.0) * p22
+        direction = np.array((1.0, vy, -vx))            # view (vx, vy, 1) as a row vector times the world rows
+        q = np.array((5.0, -3.0, 2.0)) + 20.0 * direction
+        _target(sc, q, -direction / np.linalg.norm(direction), 0, size=0.2)
+        want[(x, y)] = k
+    return sc, want
+
+
 def all_cases():
     cases = {}
     for k in ("lit", "blocker_in_the_box", "blocker_counted_twice"):

@@ -110,6 +110,21 @@ def test_hand_derived_oblique_child_rays(kind):
     assert (img[c, c, :3].astype(int) - bare[c, c, :3].astype(int)).min() >= 5
 
 
+def check_camera_ids(hit, want):
+    for (x, y), k in want.items():
+        assert hit[y, x] == k, f"pixel ({x},{y}) should see target {k}"
+    assert (hit >= 0).sum() == len(want), "a target is seen by exactly one pixel"
+
+
+def test_hand_derived_camera_rays():
+    sc, want = known_answers.camera_case()
+    v, t = sc.flatten()
+    _, hit, _ = orc.raytrace(sc, *orc.kdtree_build(v, t, 10, 2), threads=1)
+    check_camera_ids(hit, want)
+    brute, _ = orc.brute_primary_hits(sc, threads=1)
+    check_camera_ids(brute, want)
+
+
 def test_hand_derived_refraction_falloff_within_one_step():
     """exp() of the fold weight is the platform's: one 8-bit step of slack."""
     sc, want = known_answers.refraction_case(falloff=0.05)

@@ -73,6 +73,17 @@ def test_hand_derived_oblique_child_rays_on_the_gpu(kind):
     assert np.abs(img[c, c].astype(int) - np.array(want)).max() <= 1     # expectation worked out in double precision
 
 
+def test_hand_derived_camera_rays_on_the_gpu():
+    """Pixel -> ray through a turned and moved camera: every target sits where
+    the reference's ray generation sends that one pixel."""
+    sc, want = known_answers.camera_case()
+    _, ids, _, tree = hip_render(sc, 10, 2)
+    tree.release()
+    for (x, y), k in want.items():
+        assert ids[y, x] == k
+    assert (ids >= 0).sum() == len(want)
+
+
 def test_hand_derived_refraction_falloff_on_the_gpu():
     sc, want = known_answers.refraction_case(falloff=0.05)
     img, _, _, tree = hip_render(sc)
