@@ -272,8 +272,31 @@ def camera_case(w=48, h=32):
     return sc, want
 
 
+def facing_mirrors_case(stack_size):
+    """Two mirrors face each other along the centre ray (A at z = 20, B at
+    z = -10, the eye and the light between them): the ray bounces A, B, A, ...
+    until the ray budget is used up - a hit only spawns a child while
+    stackPos + 1 < STACK_SIZE (:643) - and the colours fold back child into
+    parent with the PARENT's mirror weights, clamped at every step (:688-725)."""
+    sc = _scene(f"ka_mirrors_{stack_size}", (0.0, 0.0, 0.0))
+    sc.stack_size = stack_size
+    wa, wb = (0.5, 0.5, 0.75), (0.5, 0.5, 0.5)                 # b, g, r
+    _receiver(sc, reflect=(0.0, wa[2], wa[1], wa[0]))
+    sc.materials[1] = T.make_material(COL_B, (0.0, AMB, AMB, AMB), (0.0, DIF, DIF, DIF), (1.0, 0, 0, 0),
+                                      (0.0, wb[2], wb[1], wb[0]), 0.0, 1.0)
+    _tri(sc, [(-4, -4, -10), (12, -4, -10), (-4, 12, -10)], (0, 0, 1), 1)
+    a = lit(BGR_A, 1.0, 10.0, 20.0, 0.0)
+    b = lit(BGR_B, 1.0, 10.0, 10.0, 0.0)
+    cols = [list(a if i % 2 == 0 else b) for i in range(stack_size)]
+    for i in range(stack_size - 1, 0, -1):
+        cols[i - 1] = _fold(cols[i - 1], cols[i], wa if (i - 1) % 2 == 0 else wb)
+    return sc, to_bytes(cols[0])
+
+
 def all_cases():
     cases = {}
+    for n in (1, 2, 3, 5, 6):
+        cases[f"facing_mirrors_budget_{n}"] = facing_mirrors_case(n)
     for k in ("lit", "blocker_in_the_box", "blocker_counted_twice"):
         cases["sphere_" + k] = sphere_case(k)
     for k in ("none", "opaque", "half", "two_quarters", "three_halves_clamp", "beyond_the_light"):
@@ -287,11 +310,11 @@ def all_cases():
 
 def expected(case, max_prims):
     """-> (scene, centre pixel).  One combination meets a builder rule of the
-    reference: with one triangle per leaf the two-triangle mirror scene is split
+    reference: with one triangle per leaf the two-triangle mirror scenes are split
     at z = -10, the plane the mirrored triangle lies in, and a triangle with
     min == max == sep goes to neither child (rt_funcs_render_pipe.c:1024-1027):
     it vanishes from the tree and the mirror shows nothing."""
     sc, want = all_cases()[case]
-    if case == "reflection" and max_prims == 1:
+    if (case == "reflection" or case.startswith("facing_mirrors")) and max_prims == 1:
         want = to_bytes(lit(BGR_A, 1.0, 10.0, 20.0, 0.0))
     return sc, want
