@@ -293,8 +293,55 @@ def facing_mirrors_case(stack_size):
     return sc, to_bytes(cols[0])
 
 
+def misc_case(kind):
+    sc = _scene("ka_" + kind, (0.0, -10.0, 10.0))
+    d = np.sqrt(f32(200.0))
+    side = f32(-1.0) * (f32(-10.0) / d)                 # N.L for the light at (0,-10,10)
+    mat_b = T.make_material(COL_B, (0.0, AMB, AMB, AMB), (0.0, DIF, DIF, DIF), (1.0, 0, 0, 0), (0, 0, 0, 0), 0.0, 1.0)
+    if kind == "two_lights":
+        # every light adds its clamped term to the running colour, which is clamped again (:561-562)
+        _receiver(sc)
+        sc.lights.append(scenes.make_light((0.0, 0.0, 0.0), 10.0))
+        first = lit(BGR_A, side, 10.0, d, 0.0)
+        second = lit(BGR_A, 1.0, 10.0, 20.0, 0.0)
+        return sc, to_bytes([clamp(x + y) for x, y in zip(first, second)])
+    if kind == "light_behind":
+        # max(0, N.L): only the ambient term is left (:516)
+        sc.lights[0] = scenes.make_light((0.0, 0.0, 30.0), 10.0)
+        _receiver(sc)
+        return sc, to_bytes(lit(BGR_A, 0.0, 10.0, 10.0, 0.0))
+    if kind == "total_internal_reflection":
+        # optical density 1/2 and a normal tilted by 36.9 degrees: sinT = 4 * 0.36 >= 1, no refracted ray (:664-666);
+        # the bright target straight behind A stays unseen
+        sc.lights[0] = scenes.make_light((0.0, 0.0, 0.0), 9.0)
+        _receiver(sc, col=(0.5,) + COL_A[1:], opt_dens=0.5, normal=(0.6, 0.0, -0.8))
+        sc.materials[1] = mat_b
+        _tri(sc, [(-4, -4, 30), (12, -4, 30), (-4, 12, 30)], (0, 0, -1), 1)
+        return sc, to_bytes(lit(BGR_A, 0.8, 9.0, 20.0, 0.0))
+    if kind == "inside_a_mirror_sphere":
+        # seen from inside, a sphere reports -1: the normal is flipped (:45-46) and no mirror ray is spawned (:644)
+        sc.materials[0] = T.make_material(COL_A, (0.0, AMB, AMB, AMB), (0.0, DIF, DIF, DIF), (1.0, 0, 0, 0),
+                                          (0.0, 0.5, 0.5, 0.5), 0.0, 1.0)
+        sc.materials[1] = _plain((1.0, 0, 0, 0))
+        sc.spheres.append(scenes.make_sphere((0.0, 0.0, 0.0), 20.0, 0))
+        _tri(sc, [(50, 0, 20), (52, 0, 20), (51, 2, 20)], (0, 0, -1), 1)
+        return sc, to_bytes(lit(BGR_A, side, 10.0, d, 0.0))
+    if kind == "sphere_wins_a_tie":
+        # triangle and sphere at the same distance 20: the triangle is only taken when strictly nearer (:613)
+        _receiver(sc)
+        sc.materials[1] = mat_b
+        sc.spheres.append(scenes.make_sphere((0.0, 0.0, 30.0), 10.0, 1))
+        return sc, to_bytes(lit(BGR_B, side, 10.0, d, 0.0))
+    raise ValueError(kind)
+
+
+MISC = ("two_lights", "light_behind", "total_internal_reflection", "inside_a_mirror_sphere", "sphere_wins_a_tie")
+
+
 def all_cases():
     cases = {}
+    for k in MISC:
+        cases["sphere_" + k if "sphere" in k else k] = misc_case(k)
     for n in (1, 2, 3, 5, 6):
         cases[f"facing_mirrors_budget_{n}"] = facing_mirrors_case(n)
     for k in ("lit", "blocker_in_the_box", "blocker_counted_twice"):
