@@ -682,3 +682,34 @@ def test_rays_parallel_to_an_axis_with_the_origin_in_a_split_plane(seed):
     oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
     assert np.array_equal(ids, oid) and np.array_equal(img, oimg)
     assert (st["raysClosest"], st["raysShadow"]) == (ost["raysClosest"], ost["raysShadow"])
+
+
+def test_a_frame_can_be_captured_in_a_hip_graph_and_replayed():
+    """rt_hip_render only enqueues (kernels, memsets, event fork / join between
+    its streams): a caller may capture it in a graph.  The replayed graph must
+    write the frame the direct call writes, every time."""
+    import torch
+    sc = scenes.sphere_scene(100, 80, 320, 200, reflect=0.5)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 18, 7)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        r = HipRenderer(0, stream=s.cuda_stream)
+        r.load_scene(sc, tree)
+        out = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda")
+        r.render(0, d_out=out.data_ptr())
+        s.synchronize()
+        direct = out.cpu().numpy().copy()
+        out.zero_()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            r.render(0, d_out=out.data_ptr())
+        for _ in range(2):
+            g.replay()
+            s.synchronize()
+            assert np.array_equal(out.cpu().numpy(), direct)
+            out.zero_()
+        del g
+        r.close()
+    tree.release()
+    assert direct.any()
