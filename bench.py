@@ -88,8 +88,8 @@ def cpu_baseline(sc, tree, seconds=15.0):
         # denser lattice so that the run takes about `seconds`
         step = int(max(1, min(step - 1, step * (dt / seconds) ** 0.5)))
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"every {step}th pixel of every {step}th row of the same frame on the same tree "
-                      f"({rays} rays in {dt:.1f} s)"}
+            "sample": ("the whole frame" if step == 1 else f"every {step}th pixel of every {step}th row of the same frame")
+                      + f" on the same tree ({rays} rays in {dt:.1f} s on {threads} threads)"}
 
 
 def main():
