@@ -10,7 +10,12 @@
  *   length(v)     = sqrtf(dot(v,v))
  *   normalize(v)  = v / length(v)          (three divisions)
  *   max(x,y)      = (x < y) ? y : x
- *   pow, exp, sqrt = powf, expf, sqrtf
+ *   sqrt          = sqrtf
+ *   pow, exp      = the double-precision function rounded to float, i.e. the
+ *                   correctly rounded single-precision value in all but about
+ *                   one case in 2^29 (OpenCL leaves the rounding of these two
+ *                   to the vendor; the HIP kernels compute them the same way,
+ *                   so both sides agree to the bit)
  *
  * Behaviour the reference leaves undefined is resolved as follows (the HIP
  * kernels resolve it the same way):
@@ -27,6 +32,9 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+
+static inline float cl_pow( float x, float y ) { return (float) pow( (double) x, (double) y ); }
+static inline float cl_exp( float x ) { return (float) exp( (double) x ); }
 
 typedef struct { float x, y, z; } v3;
 typedef struct { v3 src, dest, inv; } ray_t;
@@ -445,7 +453,7 @@ static rgb_t light_point( pipe_t *p, v3 P, v3 N, const rt_material *mat, v3 view
 		toLight = reflect3( toLight, N );
 		toEye = norm3( sub3( viewer, P ) );
 		ang = dot3( toEye, toLight );
-		specFact = powf( cl_max( ang, 0.0f ), mat->specular.a );
+		specFact = cl_pow( cl_max( ang, 0.0f ), mat->specular.a );
 		specular = col_mult( ld_rgb( &mat->specular ), lcol );
 		specular = col_scale( specular, specFact * L->rad / d );
 
@@ -590,9 +598,9 @@ static rgb_t raytrace_px( pipe_t *p, const ray_t *pR, int32_t *primaryHit )
 		else
 		{
 			float dist = len3( sub3( par->p, c->p ) );
-			float rr = expf( m->color.r * m->lightFalloff * -dist );
-			float rg = expf( m->color.g * m->lightFalloff * -dist );
-			float rb = expf( m->color.b * m->lightFalloff * -dist );
+			float rr = cl_exp( m->color.r * m->lightFalloff * -dist );
+			float rg = cl_exp( m->color.g * m->lightFalloff * -dist );
+			float rb = cl_exp( m->color.b * m->lightFalloff * -dist );
 
 			par->col.r += c->col.r * rr;
 			par->col.g += c->col.g * rg;

@@ -165,6 +165,14 @@ DEVI f3 cross3( f3 a, f3 b ) { return F3( a.y * b.z - a.z * b.y, a.z * b.x - a.x
 DEVI float len3( f3 a ) { return sqrtf( dot3( a, a ) ); }
 DEVI f3 norm3( f3 a ) { return div3( a, len3( a ) ); }
 DEVI float cl_max( float x, float y ) { return ( x < y ) ? y : x; }
+// pow / exp of the reference are OpenCL built-ins whose rounding is the vendor's.
+// Here: the double-precision function rounded to float - the correctly rounded
+// single-precision value in all but about one case in 2^29, and therefore the
+// same bits on any platform whose double functions are good to an ulp (the CPU
+// checker computes them the same way).  Both are off the hot path (once per
+// shaded hit and light / per refracted slot).
+DEVI float cl_pow( float x, float y ) { return (float) pow( (double) x, (double) y ); }
+DEVI float cl_exp( float x ) { return (float) exp( (double) x ); }
 // reference CL/rt_funcs_math.cl:102-105 (NaN -> lower bound)
 DEVI float clampf( float f, float b, float e ) { return ( f > b ) ? ( ( f < e ) ? f : e ) : b; }
 DEVI f3 clamp01( f3 c ) { return F3( clampf( c.x, 0.0f, 1.0f ), clampf( c.y, 0.0f, 1.0f ), clampf( c.z, 0.0f, 1.0f ) ); }
@@ -853,7 +861,7 @@ DEVI f3 fold_weight( const Work &W, int slot, uint32_t e, uint32_t pk, f3 P )
 		return F3( c.x, c.y, c.z );
 	float4 d = W.rayD[o];
 	float dist = len3( sub3( F3( d.x, d.y, d.z ), P ) );
-	return F3( expf( c.x * -dist ), expf( c.y * -dist ), expf( c.z * -dist ) );
+	return F3( cl_exp( c.x * -dist ), cl_exp( c.y * -dist ), cl_exp( c.z * -dist ) );
 }
 
 DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
@@ -1235,7 +1243,7 @@ DEVI f3 light_point( const DevScene &S, const Work &W, int slot, uint32_t h, f3 
 		toLight = reflect3( toLight, N );
 		f3 toEye = norm3( sub3( viewer, P ) );
 		ang = dot3( toEye, toLight );
-		float specFact = powf( cl_max( ang, 0.0f ), mat.specular.a );
+		float specFact = cl_pow( cl_max( ang, 0.0f ), mat.specular.a );
 		f3 specular = col_mult( rgb_of( mat.specular ), lcol );
 		specular = col_scale( specular, specFact * rad / d );
 

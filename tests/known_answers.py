@@ -149,7 +149,7 @@ def refraction_case(falloff=0.0, with_reflection=False):
     _tri(sc, [(-4, -4, 30), (12, -4, 30), (-4, 12, 30)], (0, 0, -1), 2)
     a = lit(BGR_A, 1.0, 10.0, 20.0, 0.0)
     c = lit(BGR_B, 1.0, 10.0, 30.0, 0.5)
-    w = [np.exp(f32(ch) * f32(falloff) * f32(-10.0)) for ch in BGR_A]
+    w = [f32(np.exp(np.float64(f32(ch) * f32(falloff) * f32(-10.0)))) for ch in BGR_A]
     out = _fold(a, c, w)                       # the refraction child (slot 2, or 1 without a mirror) folds first
     if with_reflection:
         sc.materials[1] = sc.materials[2]

@@ -126,7 +126,8 @@ def test_hand_derived_camera_rays():
 
 
 def test_hand_derived_refraction_falloff_within_one_step():
-    """exp() of the fold weight is the platform's: one 8-bit step of slack."""
+    """The fold weight exp(-colour * falloff * distance): one 8-bit step of slack
+    for the float32 rounding of the two hit points the hand calculation ignores."""
     sc, want = known_answers.refraction_case(falloff=0.05)
     v, t = sc.flatten()
     img, _, _ = orc.raytrace(sc, *orc.kdtree_build(v, t), threads=1)

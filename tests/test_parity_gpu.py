@@ -89,7 +89,7 @@ def test_hand_derived_refraction_falloff_on_the_gpu():
     img, _, _, tree = hip_render(sc)
     tree.release()
     c = known_answers.CENTRE
-    assert np.abs(img[c, c].astype(int) - np.array(want)).max() <= 1     # exp() is the device library's
+    assert np.abs(img[c, c].astype(int) - np.array(want)).max() <= 1     # the distance between the two hit points carries float32 rounding the hand calculation ignores
 
 
 @pytest.mark.parametrize("name", sorted(IMG))
