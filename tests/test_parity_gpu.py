@@ -713,3 +713,56 @@ def test_a_frame_can_be_captured_in_a_hip_graph_and_replayed():
         r.close()
     tree.release()
     assert direct.any()
+
+
+def test_two_contexts_interleaved_and_from_two_threads():
+    """Contexts are independent: frames enqueued alternately on two of them
+    (no synchronisation in between) and frames rendered by two host threads at
+    once, each with its own context and its own GPU tree build, are the frames
+    each scene gives on its own."""
+    import threading
+    from raytracing_amd.pipe import DeviceTree
+    scs = [scenes.sphere_scene(100, 80, 200, 150, reflect=0.5), scenes.sphere_scene(60, 50, 160, 128, reflect=0.0)]
+    alone = []
+    for sc in scs:
+        img, ids, _, tree = hip_render(sc, 16, 7, flags=RT_HIP_HITIDS)
+        tree.release()
+        alone.append((img, ids))
+
+    rs = []
+    for sc in scs:
+        v, t = sc.flatten()
+        r = HipRenderer(0)
+        r.load_scene(sc, FlatTree.build(v, t, 16, 7))
+        rs.append(r)
+    for _ in range(3):
+        for r in rs:
+            r.render(RT_HIP_HITIDS)
+    for r, (img, ids) in zip(rs, alone):
+        assert np.array_equal(r.read_frame(), img) and np.array_equal(r.read_hit_ids(), ids)
+        r.close()
+
+    out, errs = [None, None], []
+
+    def worker(i):
+        try:
+            sc = scs[i]
+            v, t = sc.flatten()
+            r = HipRenderer(0)
+            for _ in range(3):
+                r.load_scene(sc, DeviceTree.build(v, t, 16, 7))
+                r.render(RT_HIP_HITIDS)
+            out[i] = (r.read_frame(), r.read_hit_ids())
+            r.close()
+        except Exception as e:          # noqa: BLE001 - reported below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(120)
+    assert not errs, errs
+    for i in range(2):
+        assert out[i] is not None
+        assert np.array_equal(out[i][0], alone[i][0]) and np.array_equal(out[i][1], alone[i][1])
