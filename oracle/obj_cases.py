@@ -130,3 +130,91 @@ def load(lib, directory, name, with_materials=True):
                    diffuse=[float(x["diffuse"][c]) for c in "rgba"], specular=[float(x["specular"][c]) for c in "rgba"],
                    reflect=[float(x["reflect"][c]) for c in "rgb"], optDens=float(x["optDens"])) for x in mats])
     return 0, out
+
+
+def random_case(seed):
+    """-> (obj text, mtl text): a well-formed file of the kind the reference's
+    loader reads without touching memory it does not own - every object has an
+    'o' line, every corner is v/vt/vn, every face follows a usemtl - with
+    random counts, number formats, triangles and quads, comments and blank lines."""
+    rng = np.random.RandomState(seed)
+
+    def num(lo=-50.0, hi=50.0):
+        x = rng.uniform(lo, hi)
+        return [f"{x:.6f}", f"{x:.2f}", f"{x:.0f}", f"{x:e}", f"{x:+.3f}"][rng.randint(5)]
+
+    n_mat = int(rng.randint(1, 4))
+    names = [f"m{seed}_{k}" for k in range(n_mat)]
+    mtl = []
+    for nm in names:
+        mtl.append(f"newmtl {nm}")
+        keys = ["Ns", "Ka", "Kd", "Ks", "Ni", "d", "illum"]
+        if rng.rand() < 0.5:
+            keys.insert(int(rng.randint(len(keys))), "Ke")
+        for k in keys:
+            if k in ("Ka", "Kd", "Ks", "Ke"):
+                mtl.append(f"{k} {num(0, 1)} {num(0, 1)} {num(0, 1)}")
+            elif k == "illum":
+                mtl.append(f"illum {int(rng.randint(3))}")
+            else:
+                mtl.append(f"{k} {num(0, 2) if k != 'Ns' else num(1, 200)}")
+        if rng.rand() < 0.5:
+            mtl.append("")
+    obj = ["# fuzz", f"mtllib fuzz{seed}.mtl"]
+    nv = nt = nn = 0
+    for o in range(int(rng.randint(1, 4))):
+        obj.append(f"o obj{o}")
+        v0, t0, n0 = nv, nt, nn
+        for _ in range(int(rng.randint(4, 12))):
+            obj.append(f"v {num()} {num()} {num()}"); nv += 1
+        for _ in range(int(rng.randint(1, 4))):
+            obj.append(f"vt {num(0, 1)} {num(0, 1)}"); nt += 1
+        for _ in range(int(rng.randint(1, 5))):
+            obj.append(f"vn {num(-1, 1)} {num(-1, 1)} {num(-1, 1)}"); nn += 1
+        if rng.rand() < 0.3:
+            obj.append("# a comment between the tables and the faces")
+        obj.append(f"usemtl {names[rng.randint(n_mat)]}")
+        if rng.rand() < 0.3:
+            obj.append("s off")
+        for _ in range(int(rng.randint(1, 10))):
+            k = 3 if rng.rand() < 0.6 else 4
+            # corners may name vertices of this object or of an earlier one
+            vs = rng.choice(np.arange(1, nv + 1) if rng.rand() < 0.2 else np.arange(v0 + 1, nv + 1), k, replace=False)
+            obj.append("f " + " ".join(f"{int(a)}/{int(rng.randint(1, nt + 1))}/{int(rng.randint(1, nn + 1))}" for a in vs))
+    return "\n".join(obj) + "\n", "\n".join(mtl) + "\n"
+
+
+def wild_case(seed):
+    """random_case with the formatting a real exporter may produce: tabs and
+    runs of blanks, CRLF line ends, trailing blanks, a missing final newline,
+    'g' and 's' lines, a second usemtl inside an object."""
+    rng = np.random.RandomState(10_000 + seed)
+    obj, mtl = random_case(seed)
+    kind = int(rng.randint(6))
+    lines = obj.split("\n")[:-1]
+    if kind == 0:
+        lines = [l.replace(" ", "  ") if l[:2] in ("v ", "vn", "vt") else l for l in lines]
+    elif kind == 1:
+        lines = [l + " " if rng.rand() < 0.5 else l for l in lines]
+    elif kind == 2:
+        obj = "\r\n".join(lines) + "\r\n"
+        return obj, mtl.replace("\n", "\r\n")
+    elif kind == 3:
+        return "\n".join(lines), mtl                   # no newline at the end
+    elif kind == 4:
+        out = []
+        for l in lines:
+            out.append(l)
+            if l.startswith("o "):
+                out.append("g " + l[2:])
+        lines = out
+    else:
+        out, seen = [], 0
+        for l in lines:
+            if l.startswith("f "):
+                seen += 1
+                if seen % 3 == 0:
+                    out.append(next(x for x in lines if x.startswith("usemtl")))
+            out.append(l)
+        lines = out
+    return "\n".join(lines) + "\n", mtl

@@ -50,6 +50,28 @@ def test_loader_against_the_live_reference(tmp_path):
     assert as_golden(a) == as_golden(b)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_well_formed_files_against_the_live_reference(tmp_path, seed):
+    """Random objects, tables, triangles and quads, number formats, materials
+    (oracle/obj_cases.random_case; tools/fuzz_obj.py runs hundreds of them).
+    The reference never writes the normal of a vertex no face names, so only
+    the named ones are compared."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/librt_ref.so is only built where the reference sources are present")
+    obj, mtl = oc.random_case(seed)
+    (tmp_path / f"fuzz{seed}.mtl").write_text(mtl)
+    (tmp_path / "f.obj").write_text(obj)
+    out = []
+    for L in (lib(), ref.lib()):
+        rc, m = oc.load(L, str(tmp_path), "f.obj")
+        assert rc == 0
+        used = np.zeros(len(m["pos"]), bool)
+        used[m["tris"].ravel()] = True
+        out.append(as_golden(dict(m, norm=np.where(used[:, None], m["norm"], 0.0).astype(np.float32))))
+    assert out[0] == out[1]
+
+
 def test_file_without_normals_gets_them_from_the_faces(tmp_path):
     """The reference dereferences its (absent) normal table for such a file;
     here the normals are the normalised sums of (v1-v0) x (v2-v0) over the

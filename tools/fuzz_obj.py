@@ -1,0 +1,65 @@
+"""Development helper: random well-formed OBJ / MTL files through the product's loader and
+the reference's own (oracle/_ref), each case in a child process (the reference's parser is
+easily driven into memory it does not own).  Usage: python tools/fuzz_obj.py [first] [count] [wild]"""
+import multiprocessing as mp, os, sys, tempfile
+from oracle import obj_cases as oc, ref
+from raytracing_amd._lib import lib
+from tests.test_mesh_loader import as_golden
+
+
+WILD = len(sys.argv) > 3 and sys.argv[3] == "wild"
+
+
+def comparable(m):
+    """The reference leaves the normal of a vertex no face names uninitialised: not compared."""
+    if not m:
+        return None
+    import numpy as np
+    used = np.zeros(len(m["pos"]), bool)
+    used[m["tris"].ravel()] = True
+    m = dict(m, norm=np.where(used[:, None], m["norm"], 0.0).astype(np.float32))
+    return as_golden(m)
+
+
+def one(seed, q):
+    d = tempfile.mkdtemp()
+    obj, mtl = (oc.wild_case if WILD else oc.random_case)(seed)
+    open(os.path.join(d, f"fuzz{seed}.mtl"), "w").write(mtl)
+    open(os.path.join(d, "f.obj"), "w").write(obj)
+    a = oc.load(lib(), d, "f.obj")
+    q.send(("product", a[0], comparable(a[1])))
+    b = oc.load(ref.lib(), d, "f.obj")
+    q.send(("reference", b[0], comparable(b[1])))
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad = crashed = 0
+    for seed in range(first, first + count):
+        rx, q = mp.Pipe(False)
+        p = mp.Process(target=one, args=(seed, q))
+        p.start()
+        q.close()
+        got = []
+        try:
+            for _ in range(2):
+                if rx.poll(20):
+                    got.append(rx.recv())
+        except Exception:
+            pass
+        p.join(5)
+        if p.is_alive():
+            p.kill()
+        if len(got) < 2:
+            crashed += 1
+            print(f"seed {seed}: {'product' if not got else 'reference'} loader did not return (exit {p.exitcode})", flush=True)
+            bad += not got
+            continue
+        if got[0][1:] != got[1][1:]:
+            bad += 1
+            a, b = got[0][2], got[1][2]
+            diff = [k for k in a if a[k] != b[k]] if a and b else "return codes"
+            print(f"seed {seed}: MISMATCH in {diff}" + (f" (format {(__import__('numpy').random.RandomState(10_000 + seed).randint(6))})" if WILD else ""), flush=True)
+    print(f"{count} cases, {bad} mismatches, {crashed} cases in which a loader did not return")
+    sys.exit(1 if bad else 0)
