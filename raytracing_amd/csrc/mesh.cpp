@@ -25,10 +25,11 @@ namespace {
 
 bool starts( const char *s, const char *p ) { return strncmp( s, p, strlen( p ) ) == 0; }
 
+// drops the line end and blanks before it (a name ends with its last visible character)
 void chomp( char *s )
 {
 	size_t l = strlen( s );
-	while ( l && ( s[l - 1] == '\n' || s[l - 1] == '\r' ) )
+	while ( l && ( s[l - 1] == '\n' || s[l - 1] == '\r' || s[l - 1] == ' ' || s[l - 1] == '\t' ) )
 		s[--l] = '\0';
 }
 

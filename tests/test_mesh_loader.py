@@ -97,6 +97,31 @@ def test_faces_before_any_object_line_form_one_group(tmp_path):
     assert m["norm"].tolist() == [[0.0, 0.0, 1.0]] * 3
 
 
+@pytest.mark.parametrize("style", ["trailing_blanks", "crlf", "tabs"])
+def test_line_ends_and_blanks_an_exporter_may_write(tmp_path, style):
+    """Trailing blanks and CRLF line ends drive the reference's parser into
+    memory it does not own (tools/fuzz_obj.py); the product reads such files
+    as the same file without them."""
+    oc.write_case(str(tmp_path))
+    want = oc.load(lib(), str(tmp_path), "case.obj")[1]
+    lines = oc.OBJ.split("\n")[:-1]
+    mtl = oc.MTL
+    if style == "trailing_blanks":
+        text = "\n".join(l + "  " for l in lines) + "\n"
+    elif style == "crlf":
+        text = "\r\n".join(lines) + "\r\n"
+        mtl = mtl.replace("\n", "\r\n")
+    else:
+        text = "\n".join(l.replace(" ", "\t") for l in lines) + "\n"
+        mtl = mtl.replace(" ", "\t")
+    d = tmp_path / style
+    d.mkdir()
+    (d / "case.mtl").write_text(mtl, newline="")
+    (d / "case.obj").write_text(text, newline="")
+    rc, got = oc.load(lib(), str(d), "case.obj")
+    assert rc == 0 and as_golden(got) == as_golden(want)
+
+
 def test_missing_file_returns_minus_one(tmp_path):
     rc, m = oc.load(lib(), str(tmp_path), "absent.obj")
     assert rc == -1 and m is None
