@@ -114,7 +114,7 @@ static void build_water( demo_scene *sc, float t )
 			float y = sc->plHt;
 			for ( k = 0; k < 7; ++k )
 				y = (float) ( (double) y + sin( (double) g_waves[k][0] * ( -cos( (double) g_waves[k][2] ) * u
-					+ sin( (double) g_waves[k][2] ) * v ) + (double) t * g_waves[k][3] ) * g_waves[k][1] );
+					+ sin( (double) g_waves[k][2] ) * v ) + (double) (float) ( t * g_waves[k][3] ) ) * g_waves[k][1] );
 			set_vertex( &sc->water.v[i * pr + j], -sc->plSz * 0.5f + (float) i * dt, y,
 				50.0f - sc->plSz * 0.5f + (float) j * dt, 0.0f, -1.0f, 0.0f );
 		}
@@ -124,19 +124,21 @@ static void build_water( demo_scene *sc, float t )
 			set_tri( &sc->water.t[q++], pr * i + j, pr * ( i + 1 ) + j, pr * i + j + 1 );
 			set_tri( &sc->water.t[q++], pr * ( i + 1 ) + j + 1, pr * i + j + 1, pr * ( i + 1 ) + j );
 		}
-	/* corner by corner, as raytracing_amd/scenes.py accumulates them, so that both
-	 * restatements of the scene give bit-identical normals */
-	for ( k = 0; k < 3; ++k )
-		for ( q = 0; q < sc->water.tc; ++q )
+	/* triangle by triangle, each normal added to its three corners in turn: the
+	 * per-vertex fp32 summation order of the reference (main.c:398-418) */
+	for ( q = 0; q < sc->water.tc; ++q )
+	{
+		rt_triangle *tr = &sc->water.t[q];
+		rt_vertex *a = &sc->water.v[tr->pV0], *b = &sc->water.v[tr->pV1], *c = &sc->water.v[tr->pV2];
+		const float e1[3] = { b->pos.x - a->pos.x, b->pos.y - a->pos.y, b->pos.z - a->pos.z };
+		const float e2[3] = { c->pos.x - a->pos.x, c->pos.y - a->pos.y, c->pos.z - a->pos.z };
+		const float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+		rt_vertex *corner[3] = { a, b, c };
+		for ( k = 0; k < 3; ++k )
 		{
-			rt_triangle *tr = &sc->water.t[q];
-			rt_vertex *a = &sc->water.v[tr->pV0], *b = &sc->water.v[tr->pV1], *c = &sc->water.v[tr->pV2];
-			const float e1[3] = { b->pos.x - a->pos.x, b->pos.y - a->pos.y, b->pos.z - a->pos.z };
-			const float e2[3] = { c->pos.x - a->pos.x, c->pos.y - a->pos.y, c->pos.z - a->pos.z };
-			const float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
-			rt_vertex *v = k == 0 ? a : ( k == 1 ? b : c );
-			v->norm.x += n[0]; v->norm.y += n[1]; v->norm.z += n[2];
+			corner[k]->norm.x += n[0]; corner[k]->norm.y += n[1]; corner[k]->norm.z += n[2];
 		}
+	}
 	for ( q = 0; q < sc->water.vc; ++q )
 	{
 		rt_vector3 *n = &sc->water.v[q].norm;

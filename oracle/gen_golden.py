@@ -142,6 +142,9 @@ def main():
     # 4b. OBJ / MTL loader of the reference on the inputs of oracle/obj_cases.py
     write_obj_golden()
 
+    # 4c. the reference's vertex-normal rule on the demo water mesh and a closed sphere
+    write_normals_golden()
+
     # 5. regression vectors of the kernel restatement
     for name, (sc, depth, prims) in image_scenes().items():
         v, t = sc.flatten()
@@ -151,6 +154,42 @@ def main():
                             depth=depth, prims=prims, img=img, hit=hit,
                             stats=np.array([st[k] for k in ("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits")], np.uint64))
         print("orc image", name, img.shape, st)
+
+
+def restore_normals_by_reference(verts, tris):
+    """rt_restore_normals of the reference (rt_meshes.c:77-107) on a copy of
+    `verts`: adds every triangle's normal to its three vertices in turn, on top
+    of the normals already stored, then normalises.  main.c:398-423 applies the
+    same per-triangle order to the water mesh."""
+    import ctypes as C
+    from oracle import obj_cases as oc
+    v = np.ascontiguousarray(verts, T.vertex).copy()
+    t = np.ascontiguousarray(tris, T.triangle)
+    m = oc.Mesh()
+    m.v, m.t, m.vc, m.tc = v.ctypes.data, t.ctypes.data, len(v), len(t)
+    ref.lib().rt_restore_normals(C.byref(m))
+    return v
+
+
+def normals_cases():
+    """name -> (start normals, mesh) for the normal fixtures"""
+    water = scenes.default_scene(64, 48, t=0.37, squares=24).meshes[1]
+    ball = scenes.displaced_sphere_mesh(20, 16, 0)
+    return {"water24": ((0.0, -1.0, 0.0), water), "sphere640": ((0.0, 0.0, 0.0), ball)}
+
+
+def write_normals_golden():
+    """tests/golden/ref_normals.npz: vertex normals the reference's
+    rt_restore_normals gives for the positions / triangles of two meshes of
+    raytracing_amd/scenes.py (bit patterns)."""
+    out = {}
+    for name, (start, mesh) in normals_cases().items():
+        v = mesh.verts.copy()
+        v["norm"]["x"], v["norm"]["y"], v["norm"]["z"] = start
+        r = restore_normals_by_reference(v, mesh.tris)
+        out[name] = np.stack([r["norm"][k] for k in "xyz"], axis=1).astype(np.float32).view(np.uint32)
+    np.savez_compressed(os.path.join(GOLD, "ref_normals.npz"), **out)
+    print("normals golden:", {k: a.shape for k, a in out.items()})
 
 
 def write_math_golden():
@@ -186,5 +225,7 @@ if __name__ == "__main__":
         write_obj_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "math":
         write_math_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "normals":
+        write_normals_golden()
     else:
         main()

@@ -218,3 +218,36 @@ def wild_case(seed):
             out.append(l)
         lines = out
     return "\n".join(lines) + "\n", mtl
+
+
+def malformed_case(seed):
+    """random_case with its face lines rewritten at random: corners as "v",
+    "v/vt", "v//vn", relative (negative) indices, and wild ones (0, beyond the
+    vertex list, far below zero).  No reference output exists for these (its
+    parser reads past what it parsed); the product must return with every
+    stored index inside the vertex list."""
+    rng = np.random.RandomState(20_000 + seed)
+    obj, mtl = random_case(seed)
+    out = []
+    for l in obj.split("\n")[:-1]:
+        if l.startswith("f ") and rng.rand() < 0.7:
+            corners = []
+            for c in l.split()[1:]:
+                v, _, n = (c.split("/") + ["", ""])[:3]
+                kind = int(rng.randint(7))
+                if kind == 0:
+                    c = v
+                elif kind == 1:
+                    c = f"{v}/3"
+                elif kind == 2:
+                    c = f"{v}//{n or 1}"
+                elif kind == 3:
+                    c = str(-int(rng.randint(1, 4)))
+                elif kind == 4:
+                    c = str(int(rng.choice([0, 10 ** 6, -10 ** 6, 2 ** 31 - 1])))
+                elif kind == 5:
+                    c = f"{v}/{n}/"
+                corners.append(c)
+            l = "f " + " ".join(corners)
+        out.append(l)
+    return "\n".join(out) + "\n", mtl

@@ -14,7 +14,11 @@
 //     of EVERY line that has one there, so the last such line wins (normally
 //     the "d" line).
 // Unlike the reference, arrays are zero-initialised and sized by their own
-// element types.
+// element types, face corners may also be written "v", "v/vt" or "v//vn"
+// (the reference's sscanf stops at the first corner of those and leaves the
+// other indices uninitialised), negative indices count back from the last
+// vertex / normal read so far, and a face that names a vertex outside the
+// file's vertex list is dropped instead of being stored with a wild index.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +49,35 @@ long face_triangles( const char *f )
 		in = !sp;
 	}
 	return words == 3 ? 1 : words == 4 ? 2 : 0;
+}
+
+// one face corner: "v", "v/vt", "v//vn" or "v/vt/vn"; parts that are absent stay 0.
+// Returns the position after the corner, NULL when no vertex index is there.
+const char *parse_corner( const char *s, int &v, int &n )
+{
+	v = n = 0;
+	while ( *s == ' ' || *s == '\t' ) ++s;
+	char *e;
+	long a = strtol( s, &e, 10 );
+	if ( e == s )
+		return NULL;
+	v = (int) a;
+	s = e;
+	if ( *s == '/' )
+	{
+		++s;
+		(void) strtol( s, &e, 10 );               // texture index, unused
+		s = e;
+		if ( *s == '/' )
+		{
+			++s;
+			a = strtol( s, &e, 10 );
+			if ( e != s )
+				n = (int) a;
+			s = e;
+		}
+	}
+	return s;
 }
 
 char **load_mtl( rt_mesh *m, char *path )
@@ -96,6 +129,8 @@ void rt_restore_normals( rt_mesh *m )
 		exit( -1 );
 	for ( rt_ulong i = 0; i < m->tc; ++i )
 	{
+		if ( m->t[i].pV0 >= m->vc || m->t[i].pV1 >= m->vc || m->t[i].pV2 >= m->vc )
+			continue;                                 // a wild index would be a wild write
 		rt_vertex &a = m->v[m->t[i].pV0], &b = m->v[m->t[i].pV1], &c = m->v[m->t[i].pV2];
 		rt_vector3 e1, e2, n;
 		rt_vector3_sub( &a.pos, &b.pos, &e1 );        // b - a
@@ -144,8 +179,9 @@ int rt_mesh_load_from_obj( rt_mesh *m, char *path )
 		if ( n && ni >= 1 && (rt_ulong) ni <= nc && vi >= 1 && (rt_ulong) vi <= m->vc )
 			m->v[vi - 1].norm = n[ni - 1];
 	};
+	auto valid = [&]( int vi ) { return vi >= 1 && (rt_ulong) vi <= m->vc; };
 	auto emit = [&]( int a, int b, int c ) {
-		if ( curT < m->tc )
+		if ( curT < m->tc && valid( a ) && valid( b ) && valid( c ) )
 		{
 			m->t[curT].pV0 = (rt_ulong) ( a - 1 );
 			m->t[curT].pV1 = (rt_ulong) ( b - 1 );
@@ -189,21 +225,24 @@ int rt_mesh_load_from_obj( rt_mesh *m, char *path )
 		else if ( starts( buf, "f" ) )
 		{
 			chomp( buf );
-			int vi[4] = { 0 }, ti[4] = { 0 }, ni[4] = { 0 };
-			long k = face_triangles( buf + 1 );
-			if ( k == 1 )
+			int vi[4] = { 0 }, ni[4] = { 0 };
+			const long k = face_triangles( buf + 1 );
+			const int corners = k == 1 ? 3 : ( k == 2 ? 4 : 0 );
+			const char *p = buf + 1;
+			bool ok = corners != 0;
+			for ( int c = 0; c < corners && ok; ++c )
 			{
-				sscanf( buf + 2, "%d/%d/%d %d/%d/%d %d/%d/%d", vi, ti, ni, vi + 1, ti + 1, ni + 1, vi + 2, ti + 2, ni + 2 );
-				for ( int c = 0; c < 3; ++c ) corner( vi[c], ni[c] );
-				emit( vi[0], vi[1], vi[2] );
+				p = parse_corner( p, vi[c], ni[c] );
+				ok = p != NULL;
+				if ( ok && vi[c] < 0 ) vi[c] += (int) curV + 1;      // relative to the vertices read so far
+				if ( ok && ni[c] < 0 ) ni[c] += (int) curN + 1;
 			}
-			else if ( k == 2 )
+			if ( ok )
 			{
-				sscanf( buf + 2, "%d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d", vi, ti, ni, vi + 1, ti + 1, ni + 1,
-					vi + 2, ti + 2, ni + 2, vi + 3, ti + 3, ni + 3 );
-				for ( int c = 0; c < 4; ++c ) corner( vi[c], ni[c] );
+				for ( int c = 0; c < corners; ++c ) corner( vi[c], ni[c] );
 				emit( vi[0], vi[1], vi[2] );
-				emit( vi[3], vi[0], vi[2] );
+				if ( k == 2 )
+					emit( vi[3], vi[0], vi[2] );
 			}
 		}
 		else if ( starts( buf, "usemtl" ) && curG > 0 && names && strlen( buf ) > 7 )
@@ -220,6 +259,7 @@ int rt_mesh_load_from_obj( rt_mesh *m, char *path )
 		m->g[curG - 1].vc = curV - m->g[curG - 1].voffset;
 		m->g[curG - 1].tc = curT - m->g[curG - 1].toffset;
 	}
+	m->tc = curT;                                   // faces with wild indices were dropped
 	for ( rt_ulong i = 0; i < m->mc; ++i )
 	{
 		m->mat[i].color.r = m->mat[i].color.g = m->mat[i].color.b = 1.0f;

@@ -283,10 +283,11 @@ void rt_render_pipe_add_primitive( rt_render_pipe *pRp, void *pPrim, RT_PRIMITIV
 			grow_blocks( &pRp->primBlocks, PRIMS_BLOCK_SIZE, sizeof( rt_sphere ) );
 		im->spheres.push_back( *(const rt_sphere *) pPrim );
 		pRp->primsEnd += sizeof( rt_sphere );
-		++pRp->primsCount;
 	}
-	// Other primitive types are ignored: the reference records a descriptor
-	// for them but never uploads or intersects them (:234-256).
+	// Other primitive types: the reference records a descriptor and counts the
+	// primitive (:228-229, :258) but never uploads or intersects it (:234-256),
+	// so only the counter moves here.
+	++pRp->primsCount;
 }
 
 void rt_render_pipe_add_triangles( rt_render_pipe *pRp, rt_vertex *pV, rt_triangle *pTr, rt_ulong vOffset,

@@ -114,16 +114,16 @@ def _set_xyz(dst, xyz):
 
 def accumulate_normals(pos, tri_idx, start):
     """The rule of rt_restore_normals / buildPlaneOfTriangles
-    (reference rt_meshes.c:77-107, main.c:397-423): add cross(v1-v0, v2-v0)
-    of every triangle to its three vertices (sequentially, in fp32), then
-    normalise."""
+    (reference rt_meshes.c:77-107, main.c:397-423): triangle by triangle, add
+    cross(v1-v0, v2-v0) to the triangle's three vertices in turn (fp32, so the
+    per-vertex summation order is ascending triangle index), then normalise."""
     n = np.array(start, dtype=np.float32).copy()
     p = pos.astype(np.float32)
     e1 = p[tri_idx[:, 1]] - p[tri_idx[:, 0]]
     e2 = p[tri_idx[:, 2]] - p[tri_idx[:, 0]]
     c = np.cross(e1, e2).astype(np.float32)
-    for k in range(3):
-        np.add.at(n, tri_idx[:, k], c)
+    # ufunc.at applies the additions one by one in the order given
+    np.add.at(n, tri_idx.ravel(), np.repeat(c, 3, axis=0))
     ln = np.sqrt((n * n).sum(axis=1, dtype=np.float32)).astype(np.float32)
     return (n / ln[:, None]).astype(np.float32)
 
@@ -344,8 +344,10 @@ def default_scene(w=1280, h=768, t=0.0, squares=150, seed=12345):
         y = np.full(u.shape, pl_ht, np.float32)
         for per, amp, ang, spd in WAVES:
             per, amp, ang, spd = (float(np.float32(x)) for x in (per, amp, ang, spd))
+            # t * speed is a float * float product in the reference (main.c:362-364)
+            ts = float(np.float32(np.float32(t) * np.float32(spd)))
             y = (y.astype(np.float64) + np.sin(per * (-math.cos(ang) * u + math.sin(ang) * v)
-                                               + t * spd) * amp).astype(np.float32)
+                                               + ts) * amp).astype(np.float32)
         dt = np.float32(pl_sz / squares)
         pos = np.stack([np.float32(-pl_sz * 0.5) + i.astype(np.float32) * dt, y,
                         np.float32(50.0 - pl_sz * 0.5) + j.astype(np.float32) * dt],
