@@ -154,7 +154,7 @@ def main():
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world)
     frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
 
-    dbg = bool(os.environ.get("RT_BENCH_WATCHDOG"))
+    dbg = bool(os.environ.get("RT_BENCH_TRACE"))     # debugging aid: synchronise and report after every frame
 
     def step(flags=0):
         r.render(flags, d_out=frame_local.data_ptr())

@@ -320,19 +320,70 @@ def test_config2_full_size_sampled_against_oracle():
     assert img[..., 3].max() == 0 and (img[ids == -1] == 0).all()
 
 
-def test_config3_4k_sampled_against_oracle():
+@pytest.mark.parametrize("depth,prims,flags", [(32, 7, RT_HIP_HITIDS | RT_HIP_STATS), (26, 12, RT_HIP_HITIDS)])
+def test_config3_4k_sampled_against_oracle(depth, prims, flags):
     """The benchmark workload itself (1M triangles, 3840x2160, 5 rays per pixel):
-    a 1-in-24 pixel lattice against the oracle, and the ray-count identities."""
+    a 1-in-24 pixel lattice against the oracle, and the ray-count identities.
+    The second case is exactly what bench.py times: its tree limits (depth 26,
+    leaves of at most 12) and the kernels without the counting code, which for
+    frames of this size are a separately compiled build."""
     sc = scenes.config3()
-    img, ids, st, tree = hip_render(sc, 32, 7)
+    img, ids, st, tree = hip_render(sc, depth, prims, flags=flags)
     nodes, idx = tree.expand()
-    oimg, oid, _ = orc.raytrace(sc, tree.bbox, nodes, idx, x0=11, x_step=24, y0=3, y_step=24)
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx, x0=11, x_step=24, y0=3, y_step=24)
     m = np.zeros(ids.shape, bool)
     m[3::24, 11::24] = True
     same, exact = assert_parity(img, ids, oimg, oid, m)
-    assert same == 1.0
+    assert same == 1.0 and exact == 1.0
     assert sc.w * sc.h <= st["raysClosest"] <= 5 * sc.w * sc.h
     assert st["raysShadow"] == st["hits"] <= st["raysClosest"]
+    tree.release()
+
+
+def test_config5_4k_frame_sampled_against_oracle():
+    """A fly-through frame at full size: 1M triangles, 3840x2160, reflective and
+    refractive material, six ray slots filled breadth first, on the benchmark's
+    tree limits and the kernels without counting code; 1-in-24 lattice."""
+    sc = scenes.config5_frame(37)
+    img, ids, st, tree = hip_render(sc, 26, 12, flags=RT_HIP_HITIDS)
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx, x0=7, x_step=24, y0=13, y_step=24)
+    m = np.zeros(ids.shape, bool)
+    m[13::24, 7::24] = True
+    same, exact = assert_parity(img, ids, oimg, oid, m)
+    assert same == 1.0 and exact == 1.0
+    assert sc.w * sc.h < st["raysClosest"] <= 6 * sc.w * sc.h and st["raysShadow"] == st["hits"]
+    assert st["slotRays"][5] > 0                       # the budget of six is really used
+    tree.release()
+
+
+def test_default_scene_at_its_built_in_size():
+    """The reference's demo frame (main.c:19-31: 1280x768, 150x150 water quads,
+    ten spheres) at the reference's tree limits, every pixel against the oracle."""
+    sc = scenes.default_scene()
+    img, ids, st, tree = hip_render(sc, 10, 7, flags=RT_HIP_HITIDS)
+    nodes, idx = tree.expand()
+    oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx, threads=16)
+    same, exact = assert_parity(img, ids, oimg, oid)
+    assert same == 1.0 and exact == 1.0
+    assert (st["raysClosest"], st["raysShadow"]) == (ost["raysClosest"], ost["raysShadow"])
+    tree.release()
+
+
+def test_primitives_other_than_spheres_are_counted_but_never_drawn():
+    """rt_render_pipe_add_primitive (rt_funcs_render_pipe.c:209-259) counts every
+    primitive and stores only spheres."""
+    sc, depth, prims = IMG["default_small"]
+    z = np.load(os.path.join(GOLD, "orc_default_small.npz"))
+    rp = RenderPipe(sc.w, sc.h)
+    rp.set_camera(sc.camera)
+    rp.add_scene(sc)
+    plane = np.zeros(48, np.uint8)
+    end = rp._rp.primsEnd
+    rp._L.rt_render_pipe_add_primitive(__import__("ctypes").byref(rp._rp), plane.ctypes.data_as(__import__("ctypes").c_void_p), 1)
+    assert rp.counts["prims"] == 11 and rp._rp.primsEnd == end
+    assert np.array_equal(rp.draw(), z["img"])
+    rp.cleanup()
 
 
 def test_exact_reciprocal_shortcut_equals_ieee_division_for_every_float():

@@ -15,9 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(n, port):
+    # RT_BENCH_WATCHDOG only arms a stack dump + exit should a rank stop making progress; the frames
+    # run exactly as in a normal bench run: overlapped schedule (closest-hit chain + two auxiliary
+    # streams per rank), no synchronisation between frames
     env = dict(os.environ, RT_DIST_BACKEND="gloo", RT_BENCH_WATCHDOG="150", PYTHONPATH=ROOT)
-    # two processes share one device here: the in-order schedule keeps the number of busy queues small
-    args = ["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "config2", "--depth", "20", "--no-cpu-baseline", "--no-overlap"]
+    args = ["--gpus", str(n), "--steps", "6", "--warmup", "2", "--workload", "config2", "--depth", "20", "--no-cpu-baseline"]
     if n == 1:
         cmd = [sys.executable, "bench.py"] + args
     else:
