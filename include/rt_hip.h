@@ -97,6 +97,13 @@ typedef struct _rt_hip_stats
 #define RT_PARAM_OVERLAP           6   /* 0 = run every pass on one stream, in order (default 1:
                                           shadow + lighting passes on auxiliary streams)  */
 
+#define RT_PARAM_COOP_LIVE          8   /* a wave whose rays are down to this many (0..32, default 32) lets them share
+                                          its lanes (cooperative walk: several leaves of a ray per round); 0 = every
+                                          ray keeps one lane to the end.  Same image either way.                    */
+#define RT_PARAM_COOP_STACK         9   /* traversal-stack entries per ray the cooperative walk may use (0..12, default
+                                          12); a ray that needs more restarts its walk from the root.  Lower values
+                                          exist to exercise that path.  Same image either way.                      */
+
 #define RT_HIP_MAX_TREE_DEPTH 64       /* deepest tree the traversal stack admits */
 
 int  rt_hip_device_count( void );

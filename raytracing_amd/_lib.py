@@ -66,12 +66,36 @@ def build():
     subprocess.run(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")], check=True)
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so.  Two HIP runtimes in one
+    process do not work: the one that comes second finds no device.  When torch
+    is installed its copy is therefore mapped first (without importing torch), and
+    librt_amd.so's own dependency on libamdhip64 binds to it by soname, whichever
+    of the two the application happens to use first."""
+    import glob
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        for so in sorted(glob.glob(os.path.join(d, "lib", "libamdhip64.so*"))):
+            try:
+                C.CDLL(so, mode=C.RTLD_GLOBAL)
+                return
+            except OSError:
+                continue
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO):
             raise RtError(f"{SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C raytracing_amd/csrc`) first")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(SO)
         L.rt_hip_last_error.restype = C.c_char_p
         L.rt_hip_create.restype = C.c_void_p

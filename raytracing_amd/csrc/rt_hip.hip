@@ -39,6 +39,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,22 +52,22 @@
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK  12     // traversal stack entries per lane kept in LDS
 #endif
-// Resident waves per SIMD the closest-hit kernel is compiled for.  It exists
-// twice: with 128 VGPRs (nothing spilled; the passes of a small frame are
-// chains of dependent loads and gain nothing from more waves) and with 96
-// (a little spilling, one more wave per SIMD and room beside it for the
-// shadow passes; faster from RT_BIG_FRAME pixels up).
+// Resident waves per SIMD the closest-hit kernel is compiled for: 4 (128 VGPRs).
+// A second build for 5 waves (96 VGPRs, spilling to scratch) used to serve frames
+// of RT_BIG_FRAME pixels and more; with the cooperative walk in the kernel it spills
+// in the loops and is slower than this one at every size, so both names now select
+// the same build.
 #ifndef RT_WAVES_CLOSEST
 #define RT_WAVES_CLOSEST 4
 #endif
 #ifndef RT_WAVES_CLOSEST_BIG
-#define RT_WAVES_CLOSEST_BIG 5
+#define RT_WAVES_CLOSEST_BIG RT_WAVES_CLOSEST
 #endif
 #ifndef RT_BIG_FRAME
-#define RT_BIG_FRAME 4000000u
+#define RT_BIG_FRAME 0xffffffffu
 #endif
 #ifndef RT_WAVES_SHADOW
-#define RT_WAVES_SHADOW  6   // the same for the shadow kernel (80 VGPRs)
+#define RT_WAVES_SHADOW  4   // the same for the shadow kernel
 #endif
 #define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
@@ -85,6 +86,16 @@
 #endif
 #ifndef RT_RESV_BLOCK
 #define RT_RESV_BLOCK 256u   // list entries a wave reserves per atomic when the list is long
+#endif
+// Gear change of the traversal passes (see "Cooperative walk"): a wave goes over
+// to the cooperative walk once at most RT_COOP_LIVE of its lanes are still
+// walking (0 = never); short lists are dealt out in chunks of as few as
+// 2^RT_COOP_MIN_SHIFT rays per wave.
+#ifndef RT_COOP_LIVE
+#define RT_COOP_LIVE 32
+#endif
+#ifndef RT_COOP_MIN_SHIFT
+#define RT_COOP_MIN_SHIFT 2u
 #endif
 #ifndef RT_STREAM_OCC
 #define RT_STREAM_OCC 4      // blocks per CU of the streaming (non-traversal) passes
@@ -125,6 +136,7 @@ struct Counters
 	Ctr hitCount[RT_MAX_SLOTS];           // entries in the hit list of slot k
 	Ctr headShade[RT_MAX_SLOTS];          // chunk dispenser of k_light
 	Ctr headShadow[RT_MAX_SLOTS];         // chunk dispenser of k_shadow
+	uint32_t overflow;                    // a list append did not fit its buffer (host reports an error)
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
 	unsigned long long nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;   // lane-slots spent (STATS)
@@ -146,6 +158,8 @@ struct Work
 	uint32_t *stackPos;                   // last used slot of each pixel
 	int32_t *hitId;                       // optional primary hit ids
 	uint2  *spill;                        // traversal stack overflow
+	uint32_t coopLive;                    // lanes still walking at which a wave goes over to the cooperative walk (0 = never)
+	uint32_t coopCap;                     // stack entries per ray the cooperative walk may use (<= RT_LDS_STACK; less only in tests)
 	uint32_t npix, tilesX, nChunks0, spillStride;
 	uint32_t cap;                         // entries per ray list / hit list (npix + room for reservation holes)
 };
@@ -677,17 +691,524 @@ DEVI void alpha_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, float
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Cooperative walk: the rays a wave has left share its 64 lanes
+//
+// Rays are of very different length (a ray that skims the surface passes
+// through dozens of leaves), so a wave that gives every ray one lane soon
+// carries a few long rays in mostly idle lanes, one leaf per round - a chain of
+// dependent loads that idle lanes do not shorten.  Once at most half the lanes
+// are still walking, the wave changes gear: a ray owns a SEGMENT of q lanes
+// (q = 64 / rays still walking, rounded down to a power of two, so it grows as
+// rays finish) and advances up to q leaves per round:
+//
+//   seed     the segment's first lane takes the top of the ray's traversal
+//            stack (far child + exit distance, exactly what the lane-per-ray
+//            walk pushed; the entry distance is the exit distance of the last
+//            leaf visited);
+//   expand   every level, each lane replaces its inner node by the one or two
+//            children the ray passes through, front to back, compacted within
+//            the segment - the kd step of CL/rt_funcs_primitives.cl:185-251 applied to
+//            all nodes of a level at once.  Entries that no longer fit go back
+//            onto the ray's stack, farthest first, so the stack stays what the
+//            reference's stack is: the not yet visited sub-trees, nearest on
+//            top.  A segment whose entries are all leaves and that has room
+//            takes more sub-trees off the stack.  At the end the segment holds
+//            the ray's next leaves in the order the reference visits them, each
+//            with the interval the reference's walk gives it;
+//   scan     every lane tests the triangles of its leaf;
+//   resolve  the reference's sequential rule over the leaves (first leaf whose
+//            closest hit lies before the leaf's exit ends the ray; the hit flag
+//            and the triangle of earlier leaves persist), evaluated with ballots
+//            by the lane that owns the ray.
+//
+// Every node is still loaded once and every interval is the reference's, so
+// hits are the same bit for bit; what changes is that a ray's leaves are
+// scanned side by side and its sub-trees descended side by side.  Leaves
+// behind the one that ends the ray are scanned in vain; that is the price.
+//
+// Only the LDS part of a stack is shared between lanes.  A ray whose stack
+// does not fit there is RESTARTED instead: the walk begins again at the root
+// over [T, end], T = exit distance of the last leaf scanned.  With
+// V(node, a, b) = the leaf sequence of the reference's walk of `node` over
+// [a, b] (near only if split >= b, far only if split <= a, else V(near, a,
+// split) then V(far, split, b)), every boundary T between two consecutive
+// leaves is the split distance of an ancestor at which both children were
+// taken, and V(root, T, b) is the rest of V(root, a, b) behind that boundary
+// with identical intervals: at nodes where T lies in the near part the
+// comparisons come out as before (a < T < split), at the node whose split IS
+// T the walk takes the far child only (split <= T), at nodes whose far part
+// contains T likewise.  This needs ordered distances, so rays parallel to an
+// axis (see axis_parallel) never walk cooperatively.
+// ---------------------------------------------------------------------------
+#ifndef RT_COOP_POP
+#define RT_COOP_POP 64u       // sub-trees a segment takes off the stack at a time (at most its free lanes)
+#endif
+
+// exchange area of the expand step: 5 words per lane, [word * RT_BLOCK + thread]
+__shared__ uint32_t g_lds_xch[5 * RT_BLOCK];
+// rank -> lane of the rays still walking, one table per wave
+__shared__ uint32_t g_lds_owner[RT_BLOCK];
+
+DEVI float shfl_f( float x, uint32_t lane ) { return __uint_as_float( (uint32_t) __builtin_amdgcn_ds_bpermute( (int) ( lane << 2 ), (int) __float_as_uint( x ) ) ); }
+DEVI uint32_t shfl_u( uint32_t x, uint32_t lane ) { return (uint32_t) __builtin_amdgcn_ds_bpermute( (int) ( lane << 2 ), (int) x ); }
+// LDS traffic between the lanes of one wave: program order is enough for the
+// hardware (a wave's LDS instructions execute in order); this keeps the
+// compiler from moving the accesses across
+DEVI void wave_lds_sync()
+{
+	__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+	__builtin_amdgcn_wave_barrier();
+}
+
+// a lane's place in its segment
+struct Seg
+{
+	uint32_t q, start, j;                 // lanes per segment, first lane of mine, my index in it
+	unsigned long long mask, below;       // lanes of my segment / those before me
+};
+DEVI Seg make_seg( uint32_t q )
+{
+	Seg g;
+	const uint32_t l = lane_id();
+	g.q = q;
+	g.start = l & ~( q - 1u );
+	g.j = l - g.start;
+	g.mask = q >= 64u ? ~0ull : ( ( ( 1ull << q ) - 1ull ) << g.start );
+	g.below = g.mask & ( ( 1ull << l ) - 1ull );
+	return g;
+}
+
+// One entry of a segment: node `cur` with its two words (once loaded) and the
+// interval of the ray inside it.  RT_SEG_LOAD in cur = words not loaded yet.
+#define RT_SEG_LOAD 0x80000000u
+struct SegEntry { uint32_t cur, nx, ny; float tN, tF; };
+
+// Expand (see above).  In: the ray of my segment (sr), its entry distance T,
+// the number of entries on its stack (sp, in the LDS column of thread
+// `col`), restart = begin at the root over [T, tEnd] instead.  Out: lanes with
+// `have` hold a leaf each, in walk order; sp = what is left on the stack;
+// lost = the stack did not fit (its content is void, the ray restarts).
+template <bool STATS>
+DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn, float T, float tEnd, bool restart, uint32_t col, uint32_t cap,
+	SegEntry &en, bool &have, uint32_t &sp, bool &lost, Tally &tl )
+{
+	uint32_t *const xw = g_lds_xch + threadIdx.x;                  // my own slot
+	uint32_t *const xs = g_lds_xch + ( threadIdx.x - g.j );         // slot 0 of my segment
+	const uint2 *const stk = g_lds_stack + col;                    // entry k of the ray's stack: stk[k * RT_BLOCK]
+	uint2 *const stkw = g_lds_stack + col;
+	lost = false;
+	uint32_t kept = 0u;
+	have = false;
+	en.cur = 0u; en.nx = 0u; en.ny = 3u; en.tN = T; en.tF = tEnd;
+	if ( segOn && restart )
+	{
+		sp = 0u;
+		kept = 1u;
+		if ( g.j == 0u )
+		{
+			have = true;
+			en.cur = RT_SEG_LOAD;                                      // the root
+		}
+	}
+	for ( ;; )
+	{
+		// words of new entries
+		const bool fetch = have && ( en.cur & RT_SEG_LOAD ) != 0u;
+		if ( fetch )
+		{
+			en.cur &= ~RT_SEG_LOAD;
+			const uint2 n = S.nodes[en.cur];
+			en.nx = n.x;
+			en.ny = n.y;
+			if ( STATS ) ++tl.nodes;
+		}
+		const bool inner = have && ( en.ny & 3u ) != 3u;
+		const bool segInner = ( __ballot( inner ) & g.mask ) != 0ull;
+		// a segment of leaves with room takes sub-trees off the stack
+		uint32_t take = 0u;
+		if ( segOn && !segInner && !lost )
+		{
+			take = g.q - kept;
+			if ( take > sp ) take = sp;
+			if ( take > RT_COOP_POP ) take = RT_COOP_POP;
+		}
+		if ( __ballot( segInner || take != 0u ) == 0ull )
+			break;
+		// exit distance of the entry before me (entry distance of a sub-tree that joins behind it)
+		const float prevF = shfl_f( en.tF, ( g.start + ( kept ? kept - 1u : 0u ) ) & 63u );
+		if ( segInner )
+		{
+			// my entry becomes one or two entries
+			uint32_t c0 = en.cur, x0 = en.nx, y0 = en.ny, c1 = 0u, oc = have ? 1u : 0u;
+			float a0 = en.tN, b0 = en.tF, a1 = 0.0f, b1 = 0.0f;
+			if ( inner )
+			{
+				const uint32_t axis = en.ny & 3u;
+				const float sep = __uint_as_float( en.nx );
+				const float o = pick( axis, sr.src.x, sr.src.y, sr.src.z );
+				const float iv = pick( axis, sr.inv.x, sr.inv.y, sr.inv.z );
+				const float d = pick( axis, sr.dest.x, sr.dest.y, sr.dest.z );
+				const float tSplit = ( sep - o ) * iv;
+				uint32_t nearN = en.cur + 1u, farN = en.ny >> 2;
+				if ( d < 0.0f )
+				{
+					const uint32_t tmp = nearN;
+					nearN = farN;
+					farN = tmp;
+				}
+				if ( tSplit >= en.tF )
+					c0 = nearN | RT_SEG_LOAD;
+				else if ( tSplit <= en.tN )
+					c0 = farN | RT_SEG_LOAD;
+				else
+				{
+					c0 = nearN | RT_SEG_LOAD;
+					b0 = tSplit;
+					c1 = farN | RT_SEG_LOAD;
+					a1 = tSplit;
+					b1 = en.tF;
+					oc = 2u;
+				}
+			}
+			const unsigned long long m1 = __ballot( segInner && oc >= 1u ), m2 = __ballot( segInner && oc == 2u );
+			const uint32_t pos = (uint32_t) ( __popcll( m1 & g.below ) + __popcll( m2 & g.below ) );
+			const uint32_t total = (uint32_t) ( __popcll( m1 & g.mask ) + __popcll( m2 & g.mask ) );
+			// what does not fit goes back onto the stack, farthest first
+			const uint32_t over = total > g.q ? total - g.q : 0u;
+			if ( sp + over > cap )
+				lost = true;
+			if ( oc >= 1u )
+			{
+				if ( pos < g.q )
+				{
+					uint32_t *w = xs + pos;
+					w[0] = c0; w[RT_BLOCK] = x0; w[2 * RT_BLOCK] = y0; w[3 * RT_BLOCK] = __float_as_uint( a0 ); w[4 * RT_BLOCK] = __float_as_uint( b0 );
+				}
+				else if ( !lost )
+					stkw[( sp + total - 1u - pos ) * RT_BLOCK] = make_uint2( c0 & ~RT_SEG_LOAD, __float_as_uint( b0 ) );
+			}
+			if ( oc == 2u )
+			{
+				if ( pos + 1u < g.q )
+				{
+					uint32_t *w = xs + pos + 1u;
+					w[0] = c1; w[RT_BLOCK] = 0u; w[2 * RT_BLOCK] = 0u; w[3 * RT_BLOCK] = __float_as_uint( a1 ); w[4 * RT_BLOCK] = __float_as_uint( b1 );
+				}
+				else if ( !lost )
+					stkw[( sp + total - 2u - pos ) * RT_BLOCK] = make_uint2( c1 & ~RT_SEG_LOAD, __float_as_uint( b1 ) );
+			}
+			sp = lost ? 0u : sp + over;
+			kept = total < g.q ? total : g.q;
+			wave_lds_sync();
+			have = g.j < kept;
+			if ( have )
+			{
+				en.cur = xw[0]; en.nx = xw[RT_BLOCK]; en.ny = xw[2 * RT_BLOCK];
+				en.tN = __uint_as_float( xw[3 * RT_BLOCK] );
+				en.tF = __uint_as_float( xw[4 * RT_BLOCK] );
+			}
+			wave_lds_sync();
+		}
+		else if ( take != 0u )
+		{
+			// lanes kept .. kept + take - 1 take the top `take` entries, nearest (top) first
+			if ( g.j >= kept && g.j < kept + take )
+			{
+				const uint32_t k = g.j - kept;
+				const uint2 e = stk[( sp - 1u - k ) * RT_BLOCK];
+				en.cur = e.x | RT_SEG_LOAD;
+				en.tF = __uint_as_float( e.y );
+				en.tN = k ? __uint_as_float( stk[( sp - k ) * RT_BLOCK].y ) : ( kept ? prevF : T );
+				have = true;
+			}
+			sp -= take;
+			kept += take;
+		}
+	}
+}
+
+// Continues the closest-hit query of every lane with `active` set
+// cooperatively (see above).  In: the lane is about to open node t.cur over
+// [t.tNear, t.tFar] with t.sp entries on its stack; h carries the persistent
+// part of the hit state in and the result out.  Wave-uniform.
+template <bool STATS>
+DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav &t, NearHit &h, Tally &tl, uint32_t cap )
+{
+	uint32_t *const own = g_lds_owner + ( threadIdx.x & ~63u );
+	// from here on a ray is (entry distance T, stack): the node the lane was about
+	// to open goes onto its stack
+	uint32_t sp = 0u;
+	bool restart = false;
+	float T = t.tNear;
+	if ( active )
+	{
+		if ( (uint32_t) t.sp < cap )
+		{
+			g_lds_stack[t.sp * RT_BLOCK + threadIdx.x] = make_uint2( t.cur, __float_as_uint( t.tFar ) );
+			sp = (uint32_t) t.sp + 1u;
+		}
+		else
+			restart = true;                  // part of this stack lives outside LDS
+	}
+	wave_lds_sync();
+	for ( ;; )
+	{
+		const unsigned long long mA = __ballot( active );
+		if ( mA == 0ull )
+			break;
+		const uint32_t nA = (uint32_t) __popcll( mA );
+		const uint32_t lq = 31u - (uint32_t) __clz( (int) ( 64u / nA ) ), q = 1u << lq;
+		const Seg g = make_seg( q );
+		// segment s belongs to the s-th walking ray
+		const uint32_t rank = lanes_below( mA );
+		if ( active )
+			own[rank] = lane_id();
+		wave_lds_sync();
+		const uint32_t seg = lane_id() >> lq;
+		const bool segOn = seg < nA;
+		const uint32_t owner = segOn ? own[seg] : lane_id();
+		wave_lds_sync();
+		Ray sr;
+		sr.src = F3( shfl_f( r.src.x, owner ), shfl_f( r.src.y, owner ), shfl_f( r.src.z, owner ) );
+		sr.dest = F3( shfl_f( r.dest.x, owner ), shfl_f( r.dest.y, owner ), shfl_f( r.dest.z, owner ) );
+		sr.inv = F3( shfl_f( r.inv.x, owner ), shfl_f( r.inv.y, owner ), shfl_f( r.inv.z, owner ) );
+		const float sT = shfl_f( T, owner );
+		uint32_t sSp = shfl_u( sp, owner );
+		const bool sRestart = shfl_u( restart ? 1u : 0u, owner ) != 0u;
+		float sEnd = 0.0f;
+		if ( __ballot( sRestart ) != 0ull )
+		{
+			float tn;
+			(void) box_ray( S, sr, tn, sEnd );                 // the ray did hit the box when it started
+		}
+
+		SegEntry en;
+		bool have, lost;
+		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl );
+
+		// scan: my leaf, CL/rt_funcs_primitives.cl:74-111
+		const TriRay R = tri_ray( sr.src, sr.dest );
+		float lt = INFINITY;
+		NearHit lh = { INFINITY, 0.0f, 0.0f, 0u, 0 };
+		const uint32_t cnt = have ? en.ny >> 2 : 0u;
+		if ( cnt != 0u )
+		{
+			uint32_t i = en.nx;
+			const uint32_t end = i + cnt;
+			Rec r0 = load_rec( S.recs, i );
+			for ( ;; )
+			{
+				Rec r1 = load_rec( S.recs, i + 1u );
+				nearest_tri<STATS>( R, r0, lt, lh, tl );
+				if ( ++i == end ) break;
+				r0 = load_rec( S.recs, i + 1u );
+				nearest_tri<STATS>( R, r1, lt, lh, tl );
+				if ( ++i == end ) break;
+			}
+		}
+
+		// resolve, by the lane that owns the ray: the leaves of its segment in
+		// order (:168-183).  The first leaf with a hit before its exit distance
+		// ends the ray; otherwise the last leaf with any hit leaves its triangle
+		// and barycentrics behind, the running distance is that of the last leaf
+		// scanned, and the ray goes on with what is on its stack.
+		const unsigned long long bTerm = __ballot( have && lh.nearestB && lt < en.tF );
+		const unsigned long long bHit = __ballot( have && lh.nearestB != 0 );
+		const unsigned long long bHave = __ballot( have ), bLost = __ballot( lost );
+		const uint32_t s0 = rank << lq;                                  // first lane of my ray's segment
+		const unsigned long long sm = q >= 64u ? ~0ull : ( ( 1ull << q ) - 1ull );
+		const unsigned long long mTerm = ( bTerm >> s0 ) & sm, mHit = ( bHit >> s0 ) & sm;
+		const uint32_t nKept = (uint32_t) __popcll( ( bHave >> s0 ) & sm );
+		const uint32_t last = s0 + ( nKept ? nKept - 1u : 0u );
+		const uint32_t srcT = s0 + ( mTerm ? (uint32_t) __ffsll( (long long) mTerm ) - 1u : 0u );
+		const uint32_t srcH = s0 + ( mHit ? 63u - (uint32_t) __clzll( (long long) mHit ) : 0u );
+		const uint32_t src = ( mTerm ? srcT : srcH ) & 63u;
+		const float vU = shfl_f( lh.minU, src ), vV = shfl_f( lh.minV, src );
+		const uint32_t vN = shfl_u( lh.prN, src );
+		const float vT = shfl_f( lt, ( mTerm ? srcT : last ) & 63u );
+		const float lastF = shfl_f( en.tF, last & 63u );
+		const uint32_t spLeft = shfl_u( sSp, s0 & 63u );
+		if ( active )
+		{
+			if ( mTerm | mHit )
+			{
+				h.minU = vU;
+				h.minV = vV;
+				h.prN = vN;
+				h.nearestB = 1;
+			}
+			h.minT = vT;
+			restart = ( ( bLost >> s0 ) & 1ull ) != 0ull;
+			sp = spLeft;
+			T = lastF;
+			if ( mTerm || ( sp == 0u && !restart ) )
+				active = false;
+		}
+	}
+}
+
+// The shadow query walked cooperatively (see "Cooperative walk"): same expand
+// step; every lane collects the hits of its leaf that count
+// (CL/rt_funcs_primitives.cl:256-276), and the opacities are then added to the
+// ray's sum in the reference's order - leaf after leaf, triangle after
+// triangle - by passing the running sum through the lanes of the segment that
+// have hits.  In: the lane is about to open node t.cur over [t.tNear, t.tFar]
+// with t.sp entries on its stack, alpha = the sum so far.
+template <bool STATS>
+DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &t, float d, float &alpha, Tally &tl, uint32_t cap )
+{
+	uint32_t *const own = g_lds_owner + ( threadIdx.x & ~63u );
+	uint32_t sp = 0u;
+	bool restart = false;
+	float T = t.tNear;
+	// the walk ends at the light; a restarted walk must end there too
+	const float tStop = t.tFar;
+	(void) tStop;
+	if ( active )
+	{
+		if ( (uint32_t) t.sp < cap )
+		{
+			g_lds_stack[t.sp * RT_BLOCK + threadIdx.x] = make_uint2( t.cur, __float_as_uint( t.tFar ) );
+			sp = (uint32_t) t.sp + 1u;
+		}
+		else
+			restart = true;
+	}
+	wave_lds_sync();
+	for ( ;; )
+	{
+		const unsigned long long mA = __ballot( active );
+		if ( mA == 0ull )
+			break;
+		const uint32_t nA = (uint32_t) __popcll( mA );
+		const uint32_t lq = 31u - (uint32_t) __clz( (int) ( 64u / nA ) ), q = 1u << lq;
+		const Seg g = make_seg( q );
+		const uint32_t rank = lanes_below( mA );
+		if ( active )
+			own[rank] = lane_id();
+		wave_lds_sync();
+		const uint32_t seg = lane_id() >> lq;
+		const bool segOn = seg < nA;
+		const uint32_t owner = segOn ? own[seg] : lane_id();
+		wave_lds_sync();
+		Ray sr;
+		sr.src = F3( shfl_f( r.src.x, owner ), shfl_f( r.src.y, owner ), shfl_f( r.src.z, owner ) );
+		sr.dest = F3( shfl_f( r.dest.x, owner ), shfl_f( r.dest.y, owner ), shfl_f( r.dest.z, owner ) );
+		sr.inv = F3( shfl_f( r.inv.x, owner ), shfl_f( r.inv.y, owner ), shfl_f( r.inv.z, owner ) );
+		const float sT = shfl_f( T, owner ), sD = shfl_f( d, owner );
+		float run = shfl_f( alpha, owner );
+		uint32_t sSp = shfl_u( sp, owner );
+		const bool sRestart = shfl_u( restart ? 1u : 0u, owner ) != 0u;
+		float sEnd = 0.0f;
+		if ( __ballot( sRestart ) != 0ull )
+		{
+			// as at the start of the query: the scene box, cut at the light
+			float tn;
+			(void) box_ray( S, sr, tn, sEnd );
+			if ( sD < sEnd ) sEnd = sD;
+		}
+
+		SegEntry en;
+		bool have, lost;
+		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl );
+
+		// scan: the hits of my leaf that count, in triangle order; the first two
+		// opacities are kept, a leaf with more is scanned again when its turn comes
+		const TriRay R = tri_ray( sr.src, sr.dest );
+		uint32_t nh = 0u;
+		float a0 = 0.0f, a1 = 0.0f;
+		const uint32_t cnt = have ? en.ny >> 2 : 0u;
+		for ( uint32_t i = 0u; i < cnt; ++i )
+		{
+			const Rec rc = load_rec( S.recs, en.nx + i );
+			float tt, u, v;
+			if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
+			if ( ray_tri( R, rc, tt, u, v ) && ( tt < sD ) && ( tt < en.tF ) && ( tt > en.tN ) )
+			{
+				const float a = S.mats[rec_mat( rc )].color.a;
+				if ( nh == 0u ) a0 = a;
+				else if ( nh == 1u ) a1 = a;
+				++nh;
+			}
+		}
+
+		// resolve: the running sum goes through the lanes with hits, in order
+		unsigned long long mine = __ballot( nh != 0u ) & g.mask;
+		while ( __ballot( mine != 0ull ) != 0ull )
+		{
+			const uint32_t turn = mine ? (uint32_t) __ffsll( (long long) mine ) - 1u : lane_id();
+			float sum = run;
+			if ( mine != 0ull && lane_id() == turn )
+			{
+				if ( nh <= 2u )
+				{
+					sum += a0;
+					if ( nh == 2u ) sum += a1;
+				}
+				else
+				{
+					for ( uint32_t i = 0u; i < cnt; ++i )
+					{
+						const Rec rc = load_rec( S.recs, en.nx + i );
+						float tt, u, v;
+						if ( ray_tri( R, rc, tt, u, v ) && ( tt < sD ) && ( tt < en.tF ) && ( tt > en.tN ) )
+							sum += S.mats[rec_mat( rc )].color.a;
+					}
+				}
+			}
+			run = shfl_f( sum, turn );
+			mine &= mine - 1ull;
+		}
+
+		const unsigned long long bHave = __ballot( have ), bLost = __ballot( lost );
+		const uint32_t s0 = rank << lq;
+		const unsigned long long sm = q >= 64u ? ~0ull : ( ( 1ull << q ) - 1ull );
+		const uint32_t nKept = (uint32_t) __popcll( ( bHave >> s0 ) & sm );
+		const uint32_t last = s0 + ( nKept ? nKept - 1u : 0u );
+		const float lastF = shfl_f( en.tF, last & 63u );
+		const uint32_t spLeft = shfl_u( sSp, s0 & 63u );
+		const float total = shfl_f( run, s0 & 63u );
+		if ( active )
+		{
+			alpha = total;
+			restart = ( ( bLost >> s0 ) & 1ull ) != 0ull;
+			sp = spLeft;
+			T = lastF;
+			// the caller clamps the sum to [0,1]: with non-negative opacities it cannot
+			// drop below 1 again
+			if ( ( S.alphaMonotone && alpha >= 1.0f ) || ( sp == 0u && !restart ) )
+				active = false;
+		}
+	}
+}
+
 // Closest-hit query of every lane with `live` set, CL/rt_funcs_primitives.cl:165-252:
 // rounds of descend / leaf scan / pop.  The per-leaf reset of the running
 // distance while the hit flag and the triangle id persist is the reference's
 // behaviour.  Control flow is wave-uniform, so that lanes whose ray is
 // finished stay available for the cooperative scans.
+//
+// coopLive: once at most that many lanes are still walking (and at least one
+// round has been walked, or `atOnce`), the rest of the rays is walked
+// cooperatively (nearest_coop); 0 = never.  Rays parallel to an axis always
+// keep their own lane.
 template <bool STATS>
-DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl )
+DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl,
+	uint32_t coopLive, uint32_t coopCap, bool atOnce )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
+	const bool mayCoop = coopLive != 0u && !axis_parallel( r );
+	bool walked = atOnce;
 	while ( __ballot( live ) != 0ull )
 	{
+		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && mayCoop ) != 0ull )
+		{
+			nearest_coop<STATS>( S, r, live && mayCoop, t, h, tl, coopCap );
+			live = live && !mayCoop;
+			continue;
+		}
+		walked = true;
 		float lt = INFINITY;
 		uint32_t cnt = 0u;
 		if ( live )
@@ -732,11 +1253,21 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 
 // shadow query of every lane with `live` set, CL/rt_funcs_primitives.cl:295-378
 template <bool STATS>
-DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, float d, float &alpha, Tally &tl )
+DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, float d, float &alpha, Tally &tl,
+	uint32_t coopLive, uint32_t coopCap, bool atOnce )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
+	const bool mayCoop = coopLive != 0u && !axis_parallel( r );
+	bool walked = atOnce;
 	while ( __ballot( live ) != 0ull )
 	{
+		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && mayCoop ) != 0ull )
+		{
+			alpha_coop<STATS>( S, r, live && mayCoop, t, d, alpha, tl, coopCap );
+			live = live && !mayCoop;
+			continue;
+		}
+		walked = true;
 		uint32_t cnt = 0u;
 		if ( live )
 		{
@@ -907,9 +1438,10 @@ DEVI StackRef make_stack( const Work &W )
 // traversal passes (2 chunks +3 %, 8 chunks +27 %); narrower chunks for short
 // lists (the long rays of the deep slots are not shortened by them).
 struct Grab { uint32_t round; };
-DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_t &first, uint32_t dynShare )
+DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_t &first, uint32_t dynShare, uint32_t shift = 6u )
 {
-	const uint32_t chunks = (uint32_t) ( ( total + 63ull ) >> 6 );
+	// a chunk is 2^shift entries (64, one per lane, except in the cooperative pass)
+	const uint32_t chunks = (uint32_t) ( ( total + ( 1ull << shift ) - 1ull ) >> shift );
 	const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
 	const uint32_t wave = blockIdx.x * ( RT_BLOCK / 64u ) + ( threadIdx.x >> 6 );
 	// dynShare = 8: one static round, the rest through the counter
@@ -931,7 +1463,7 @@ DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_
 			k = atomicAdd( head, 1u );
 		c = base + wave_bcast( k );
 	}
-	first = c * 64u;
+	first = c << shift;
 	return c < chunks;
 }
 
@@ -946,8 +1478,10 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 			continue;
 		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
 		uint32_t idx = list_append( &W.ctr->rayCount[s].v, rv[s], mine, block,
-			[&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
-		if ( mine )
+			[&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
+		if ( mine && idx >= W.cap )
+			W.ctr->overflow = 2u;                    // (2 = ray list) reported by the host; the ray is dropped
+		else if ( mine )
 		{
 			size_t o = lbase + idx;
 			W.rayA[o] = make_float4( r.src.x, r.src.y, r.src.z, __uint_as_float( pix ) );
@@ -962,163 +1496,231 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 // ---------------------------------------------------------------------------
 // k_closest: closest-hit pass of one slot
 // ---------------------------------------------------------------------------
+
+// list positions a wave has reserved for what a closest-hit pass appends
+struct ClosestOut
+{
+	Resv hits;                    // hit list of the slot
+	Resv rays[RT_MAX_SLOTS];      // ray lists of the child slots
+	uint32_t block;
+};
+
+DEVI void closest_out_close( const Work &W, int slot, ClosestOut &o )
+{
+	const size_t hbase = (size_t) slot * W.cap;
+	list_close( o.hits, [&]( uint32_t i ) { if ( i < W.cap ) W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); } );
+#pragma unroll
+	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
+	{
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
+		list_close( o.rays[s], [&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
+	}
+}
+
+// all spheres, CL/rt_funcs_primitives.cl:381-416
+struct SphereHit { float t; uint32_t n; int b; };
+DEVI SphereHit nearest_sphere( const DevScene &S, const Ray &r )
+{
+	SphereHit sh = { INFINITY, 0u, 0 };
+	for ( int i = 0; i < S.nSpheres; ++i )
+	{
+		float ts;
+		int b = ray_sphere( r, S.spheres[i], ts );
+		if ( b && ts < sh.t )
+		{
+			sh.t = ts;
+			sh.n = (uint32_t) i;
+			sh.b = b;
+		}
+	}
+	return sh;
+}
+
+// What follows the closest-hit query of ray-list entry `e` (CL/rt_funcs_primitives.cl:611-677):
+// sphere against triangle, the hit record, the shading normal, the child rays, or
+// the finished slot of a miss.  Wave-uniform: every lane of the wave calls it,
+// lanes without a ray with valid = false.
+DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantIds, ClosestOut &out,
+	bool valid, uint32_t e, const RayHead &rh, const NearHit &h, const SphereHit &sph )
+{
+	const size_t hbase = (size_t) slot * W.cap;
+	auto holeHit = [&]( uint32_t i ) { if ( i < W.cap ) W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); };
+	const float prMinT = sph.t;
+	const uint32_t prN = sph.n;
+	const int prB = sph.b;
+	// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
+	// "flag set, no valid distance, no sphere" is shaded as a miss
+	const bool triHit = valid && ( h.nearestB || prB ) && ( h.minT < prMinT );
+	const bool sphHit = valid && ( h.nearestB || prB ) && !( h.minT < prMinT ) && prB;
+	bool hit = triHit || sphHit;
+
+	const uint32_t hidx = list_append( &W.ctr->hitCount[slot].v, out.hits, hit, out.block, holeHit );
+	if ( hit && hidx >= W.cap )
+	{
+		W.ctr->overflow = 1u;                        // (1 = hit list) reported by the host; the entry is dropped
+		hit = false;
+		valid = false;
+	}
+	bool pushRefl = false, pushRefr = false;
+	Ray rRefl, rRefr;
+	f3 P = F3( 0.0f, 0.0f, 0.0f ), cRefl = P, cRefr = P;
+	int sp = 0;
+	if ( hit )
+	{
+		const size_t ho = hbase + hidx;
+		const float tHit = triHit ? h.minT : prMinT;
+		const uint32_t id = triHit ? h.prN : ( prN | 0x80000000u );
+		const int bNearest = triHit ? h.nearestB : prB;
+		W.hitA[ho] = make_float4( __uint_as_float( e ), tHit, h.minU, h.minV );
+		W.hitB[ho] = make_uint2( id, (uint32_t) bNearest );
+
+		// shading normal and child rays of the hit (the next slot's closest-hit pass
+		// waits for nothing else)
+		f3 N;
+		uint32_t matIdx;
+		// hit point: dest * t + src for triangles (:66) and spheres (:42-43) alike
+		P = add3( mul3( rh.ray.dest, tHit ), rh.ray.src );
+		if ( id & 0x80000000u )
+		{
+			// sphere normal, CL/rt_funcs_primitives.cl:45-46
+			const uint32_t si = id & 0x7fffffffu;
+			const float4 sp4 = S.spheres[si];
+			matIdx = S.sphereMat[si];
+			N = div3( sub3( P, F3( sp4.x, sp4.y, sp4.z ) ), sp4.w );
+			N = mul3( N, (float) bNearest );
+		}
+		else
+		{
+			// barycentric normal (not normalised), :68-71
+			const float4 *sp4 = S.shade + 3u * (size_t) id;
+			const float4 a = sp4[0], b = sp4[1], c = sp4[2];
+			const f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
+			const float u = h.minU, v = h.minV;
+			matIdx = __float_as_uint( c.y );
+			N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
+		}
+		W.hitN[ho] = make_float4( N.x, N.y, N.z, __uint_as_float( matIdx ) );
+
+		const rt_material &mat = S.mats[matIdx];
+		const f3 refl = rgb_of( mat.reflect );
+		const float alpha = mat.color.a;
+
+		sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
+
+		// reflection ray :643-655
+		if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 ) && ( ( refl.x + refl.y + refl.z ) > 0.0f ) )
+		{
+			++sp;
+			pushRefl = true;
+			rRefl.dest = reflect3( rh.ray.dest, N );
+			rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
+			cRefl = refl;
+		}
+		// refraction ray :657-677
+		if ( ( ( sp + 1 ) < S.stackSize ) && ( alpha < 0.99f ) )
+		{
+			const float nRel = ENV_OPT_DENSITY / mat.optDens;
+			const float cosI = dot3( N, rh.ray.dest );
+			const float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
+			if ( sinT < 1.0f )
+			{
+				++sp;
+				pushRefr = true;
+				rRefr.dest = norm3( sub3( mul3( rh.ray.dest, nRel ),
+					mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
+				rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
+				const float lf = mat.lightFalloff;
+				cRefr = F3( mat.color.r * lf, mat.color.g * lf, mat.color.b * lf );
+			}
+		}
+		if ( slot == 0 || pushRefl || pushRefr )
+			W.stackPos[rh.pix] = (uint32_t) sp;
+	}
+	// slot numbers: reflection takes the first new slot, refraction the next
+	push_ray( W, out.rays, out.block, sp - ( pushRefr ? 1 : 0 ), pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
+	push_ray( W, out.rays, out.block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
+	if ( !hit && valid )
+	{
+		const size_t o = (size_t) slot * W.npix + rh.pix;
+		W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( parent_of( rh.pk ) ) );
+		if ( slot == 0 )
+			W.stackPos[rh.pix] = 0u;
+		else
+		{
+			f3 fw = fold_weight( W, slot, e, rh.pk, F3( 0.0f, 0.0f, 0.0f ) );
+			W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
+		}
+	}
+	if ( slot == 0 && wantIds && valid )
+		W.hitId[rh.pix] = triHit ? (int32_t) h.prN : ( sphHit ? -2 - (int32_t) prN : -1 );
+}
+
+// number of entries of ray list `slot` (reservation holes included); never beyond the buffer
+DEVI uint32_t ray_list_count( const Work &W, int slot )
+{
+	if ( slot == 0 )
+		return W.nChunks0 * 64u;
+	const uint32_t n = W.ctr->rayCount[slot].v;
+	return n < W.cap ? n : W.cap;
+}
+DEVI uint32_t hit_list_count( const Work &W, int slot )
+{
+	const uint32_t n = W.ctr->hitCount[slot].v;
+	return n < W.cap ? n : W.cap;
+}
+
+// rays a wave takes per chunk of a list of `count` entries, as a power of two:
+// 64 (one per lane) when that keeps every resident wave busy, fewer for short
+// lists, so that the rays are spread over the chip and walk cooperatively
+// from the start with the lanes that would otherwise idle
+DEVI uint32_t chunk_shift( uint32_t count, uint32_t coopLive )
+{
+	uint32_t shift = 6u;
+	if ( coopLive != 0u )
+	{
+		const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
+		while ( shift > RT_COOP_MIN_SHIFT && ( ( count + ( 1u << shift ) - 1u ) >> shift ) < waves ) --shift;
+	}
+	return shift;
+}
+
 template <bool STATS, int WAVES>
 __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work W, int slot, int wantIds )
 {
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
-	const uint32_t count = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
+	const uint32_t count = ray_list_count( W, slot );
+	const uint32_t shift = slot == 0 ? 6u : chunk_shift( count, W.coopLive );   // slot 0 is dealt out in 8x8 pixel tiles
 	uint32_t first;
 	Grab grab = { 0u };
-	Resv resv = { 0u, 0u };
-	Resv rv[RT_MAX_SLOTS] = {};
-	const uint32_t block = resv_block( count );
-	const size_t hbase = (size_t) slot * W.cap;
-	auto holeHit = [&]( uint32_t i ) { W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); };
-	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_DYN ) )
+	ClosestOut out = {};
+	out.block = resv_block( count );
+	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_DYN, shift ) )
 	{
 		const uint32_t e = first + lane_id();
 		RayHead rh;
 		rh.pix = rh.pk = 0u;
-		const bool valid = load_ray( S, W, slot, e, count, rh );
+		const bool valid = lane_id() < ( 1u << shift ) && load_ray( S, W, slot, e, count, rh );
 
-		float prMinT = INFINITY;
-		uint32_t prN = 0u;
-		int prB = 0;
+		SphereHit sph = { INFINITY, 0u, 0 };
 		NearHit h = { INFINITY, 0.0f, 0.0f, 0u, 0 };
 		Trav t;
 		bool live = false;
 
 		if ( valid )
 		{
-			// all spheres, CL/rt_funcs_primitives.cl:381-416
-			for ( int i = 0; i < S.nSpheres; ++i )
-			{
-				float ts;
-				int b = ray_sphere( rh.ray, S.spheres[i], ts );
-				if ( b && ts < prMinT )
-				{
-					prMinT = ts;
-					prN = (uint32_t) i;
-					prB = b;
-				}
-			}
+			sph = nearest_sphere( S, rh.ray );
 			// Neighbouring lanes carry neighbouring rays and walk the tree in step,
 			// so their node and record loads fall into the same cache lines.
 			// (Refilling finished lanes with fresh rays mid-flight was measured and
 			// halves the speed on this workload: it destroys exactly that locality.)
 			live = trav_begin<STATS>( S, rh.ray, t, tl );
 		}
-		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl );
-
-		// CL/rt_funcs_primitives.cl:611-633: triangle wins only if strictly closer;
-		// "flag set, no valid distance, no sphere" is shaded as a miss
-		const bool triHit = valid && ( h.nearestB || prB ) && ( h.minT < prMinT );
-		const bool sphHit = valid && ( h.nearestB || prB ) && !( h.minT < prMinT ) && prB;
-		const bool hit = triHit || sphHit;
-
-		const uint32_t hidx = list_append( &W.ctr->hitCount[slot].v, resv, hit, block, holeHit );
-		bool pushRefl = false, pushRefr = false;
-		Ray rRefl, rRefr;
-		f3 P = F3( 0.0f, 0.0f, 0.0f ), cRefl = P, cRefr = P;
-		int sp = 0;
-		if ( hit )
-		{
-			const size_t ho = hbase + hidx;
-			const float tHit = triHit ? h.minT : prMinT;
-			const uint32_t id = triHit ? h.prN : ( prN | 0x80000000u );
-			const int bNearest = triHit ? h.nearestB : prB;
-			W.hitA[ho] = make_float4( __uint_as_float( e ), tHit, h.minU, h.minV );
-			W.hitB[ho] = make_uint2( id, (uint32_t) bNearest );
-
-			// shading normal and child rays of the hit (the next slot's closest-hit pass
-			// waits for nothing else)
-			f3 N;
-			uint32_t matIdx;
-			// hit point: dest * t + src for triangles (:66) and spheres (:42-43) alike
-			P = add3( mul3( rh.ray.dest, tHit ), rh.ray.src );
-			if ( id & 0x80000000u )
-			{
-				// sphere normal, CL/rt_funcs_primitives.cl:45-46
-				const uint32_t si = id & 0x7fffffffu;
-				const float4 sph = S.spheres[si];
-				matIdx = S.sphereMat[si];
-				N = div3( sub3( P, F3( sph.x, sph.y, sph.z ) ), sph.w );
-				N = mul3( N, (float) bNearest );
-			}
-			else
-			{
-				// barycentric normal (not normalised), :68-71
-				const float4 *sp4 = S.shade + 3u * (size_t) id;
-				const float4 a = sp4[0], b = sp4[1], c = sp4[2];
-				const f3 n0 = F3( a.x, a.y, a.z ), n1 = F3( a.w, b.x, b.y ), n2 = F3( b.z, b.w, c.x );
-				const float u = h.minU, v = h.minV;
-				matIdx = __float_as_uint( c.y );
-				N = add3( add3( mul3( n1, u ), mul3( n2, v ) ), mul3( n0, 1.0f - u - v ) );
-			}
-			W.hitN[ho] = make_float4( N.x, N.y, N.z, __uint_as_float( matIdx ) );
-
-			const rt_material &mat = S.mats[matIdx];
-			const f3 refl = rgb_of( mat.reflect );
-			const float alpha = mat.color.a;
-
-			sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
-
-			// reflection ray :643-655
-			if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 ) && ( ( refl.x + refl.y + refl.z ) > 0.0f ) )
-			{
-				++sp;
-				pushRefl = true;
-				rRefl.dest = reflect3( rh.ray.dest, N );
-				rRefl.src = add3( P, mul3( rRefl.dest, EPSILON ) );
-				cRefl = refl;
-			}
-			// refraction ray :657-677
-			if ( ( ( sp + 1 ) < S.stackSize ) && ( alpha < 0.99f ) )
-			{
-				const float nRel = ENV_OPT_DENSITY / mat.optDens;
-				const float cosI = dot3( N, rh.ray.dest );
-				const float sinT = nRel * nRel * ( 1.0f - cosI * cosI );
-				if ( sinT < 1.0f )
-				{
-					++sp;
-					pushRefr = true;
-					rRefr.dest = norm3( sub3( mul3( rh.ray.dest, nRel ),
-						mul3( N, nRel * cosI + sqrtf( 1.0f - sinT ) ) ) );
-					rRefr.src = add3( P, mul3( rRefr.dest, EPSILON ) );
-					const float lf = mat.lightFalloff;
-					cRefr = F3( mat.color.r * lf, mat.color.g * lf, mat.color.b * lf );
-				}
-			}
-			if ( slot == 0 || pushRefl || pushRefr )
-				W.stackPos[rh.pix] = (uint32_t) sp;
-		}
-		// slot numbers: reflection takes the first new slot, refraction the next
-		push_ray( W, rv, block, sp - ( pushRefr ? 1 : 0 ), pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
-		push_ray( W, rv, block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
-		if ( !hit && valid )
-		{
-			const size_t o = (size_t) slot * W.npix + rh.pix;
-			W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( parent_of( rh.pk ) ) );
-			if ( slot == 0 )
-				W.stackPos[rh.pix] = 0u;
-			else
-			{
-				f3 fw = fold_weight( W, slot, e, rh.pk, F3( 0.0f, 0.0f, 0.0f ) );
-				W.fac[o] = make_float4( fw.x, fw.y, fw.z, 0.0f );
-			}
-		}
-		if ( slot == 0 && wantIds && valid )
-			W.hitId[rh.pix] = triHit ? (int32_t) h.prN : ( sphHit ? -2 - (int32_t) prN : -1 );
+		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive, W.coopCap, shift < 6u );
+		finish_closest( S, W, slot, wantIds, out, valid, e, rh, h, sph );
 	}
-	list_close( resv, holeHit );
-#pragma unroll
-	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
-	{
-		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
-		list_close( rv[s], [&]( uint32_t i ) { W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
-	}
+	closest_out_close( W, slot, out );
 	if ( STATS )
 		flush_tally( W, tl, false );
 }
@@ -1146,15 +1748,16 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScen
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
-	const uint32_t hits = W.ctr->hitCount[slot].v;
-	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
+	const uint32_t hits = hit_list_count( W, slot );
+	const uint32_t rayCount = ray_list_count( W, slot );
 	const uint32_t total = hits * (uint32_t) S.nLights;      // < 2^31, checked by the host
+	const uint32_t shift = chunk_shift( total, W.coopLive );
 	uint32_t first;
 	Grab grab = { 0u };
-	while ( next_chunk( &W.ctr->headShadow[slot].v, total, grab, first, RT_TRAV_DYN ) )
+	while ( next_chunk( &W.ctr->headShadow[slot].v, total, grab, first, RT_TRAV_DYN, shift ) )
 	{
 		const uint32_t i = first + lane_id();
-		bool item = i < total;
+		bool item = lane_id() < ( 1u << shift ) && i < total;
 		uint32_t o = 0u, hh = 0u;
 		float4 ha = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
 		RayHead rh;
@@ -1203,7 +1806,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScen
 				}
 			}
 		}
-		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl );
+		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive, W.coopCap, shift < 6u );
 		if ( item )
 			W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
@@ -1259,8 +1862,8 @@ DEVI f3 light_point( const DevScene &S, const Work &W, int slot, uint32_t h, f3 
 // k_closest's normals) and the weight of the slot in its parent
 __global__ __launch_bounds__( RT_BLOCK ) void k_light( DevScene S, Work W, int slot )
 {
-	const uint32_t count = W.ctr->hitCount[slot].v;
-	const uint32_t rayCount = slot == 0 ? W.nChunks0 * 64u : W.ctr->rayCount[slot].v;
+	const uint32_t count = hit_list_count( W, slot );
+	const uint32_t rayCount = ray_list_count( W, slot );
 	const size_t base = (size_t) slot * W.cap;
 	uint32_t first;
 	Grab grab = { 0u };
@@ -1411,6 +2014,8 @@ struct rt_hip_ctx
 	bool workDirty = true;
 	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
 	int gridShadow[2] = { 0, 0 }, gridLight = 0;
+	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK;
+	uint32_t bigFrame = RT_BIG_FRAME;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[RT_AUX_STREAMS] = {};        // shadow + lighting passes (slot k on stream k mod RT_AUX_STREAMS)
 	hipEvent_t evHit[RT_MAX_SLOTS] = {}, evLit[RT_MAX_SLOTS] = {};
@@ -1519,6 +2124,12 @@ rt_hip_ctx *rt_hip_create( int device )
 		if ( k.occ ) *k.occ = occ;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
 	}
+	// development knob
+	if ( const char *v = getenv( "RT_COOP_LIVE" ) ) c->coopLive = atoi( v );
+	if ( c->coopLive < 0 || c->coopLive > 32 ) c->coopLive = 0;
+	if ( const char *v = getenv( "RT_COOP_SHADOW" ) ) c->coopShadow = atoi( v );
+	if ( const char *v = getenv( "RT_COOP_CLOSEST" ) ) c->coopClosest = atoi( v );
+	if ( const char *v = getenv( "RT_BIG_FRAME" ) ) c->bigFrame = (uint32_t) atoll( v );
 	// a streaming pass gains nothing from more than a few waves per SIMD
 	if ( c->gridLight > RT_STREAM_OCC * c->numCU ) c->gridLight = RT_STREAM_OCC * c->numCU;
 
@@ -1795,13 +2406,46 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 		c->overlap = value ? 1 : 0;
 		return 0;
 	}
+	if ( key == RT_PARAM_COOP_LIVE )
+	{
+		if ( value < 0 || value > 32 ) return fail( "RT_PARAM_COOP_LIVE must be 0..32" );
+		c->coopLive = value;
+		return 0;
+	}
+	if ( key == RT_PARAM_COOP_STACK )
+	{
+		if ( value < 0 || value > RT_LDS_STACK ) return fail( "RT_PARAM_COOP_STACK must be 0..%d", RT_LDS_STACK );
+		c->coopCap = value;
+		return 0;
+	}
 	return fail( "rt_hip_set_param: unknown key %d", key );
 }
 
+// Entries per ray / hit / hand-over list.  A list holds at most npix valid
+// entries.  Long lists are appended through wave-private reservations of
+// RT_RESV_BLOCK entries: a reservation is given up with fewer than 64 of its
+// entries unused (hence the 4/3), and every wave of every launch that appends to
+// the list can leave one unfinished reservation behind.  A ray list is fed by
+// the closest-hit passes of up to four parent slots.
+// Reservations are only used by launches whose input has at least 256 entries
+// per wave, so small frames need no room for them.  Appends check the capacity
+// on the device all the same (Counters::overflow).
 static size_t list_capacity( const rt_hip_ctx *c, size_t npix )
 {
 	static_assert( RT_RESV_BLOCK >= 256u || RT_RESV_BLOCK == 0u, "the 4/3 bound below assumes blocks of at least 256 entries" );
-	return npix + npix / 3 + 64 + (size_t) c->maxGrid * ( RT_BLOCK / 64 ) * RT_RESV_BLOCK;
+	size_t cap = npix + npix / 3 + 64;
+	const size_t wavesPerLaunch = (size_t) c->maxGrid * ( RT_BLOCK / 64 );
+	if ( npix >= 256 )
+	{
+		// launches with reservations need count >= waves * 256; grids never exceed maxGrid
+		size_t waves = cap / 256 + 1;
+		if ( waves > wavesPerLaunch ) waves = wavesPerLaunch;
+		int feeders = c->S.stackSize - 1;
+		if ( feeders > 4 ) feeders = 4;
+		if ( feeders < 1 ) feeders = 1;
+		cap += (size_t) feeders * waves * RT_RESV_BLOCK;
+	}
+	return cap;
 }
 
 static int prepare_work( rt_hip_ctx *c )
@@ -1889,7 +2533,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
 	hipEvent_t *evFold = ev + 6 * RT_MAX_SLOTS, *evFrame = evFold + 2;
 	const bool overlap = c->overlap && S.stackSize > 1;
-	const bool big = W.npix >= RT_BIG_FRAME;
+	const bool big = W.npix >= c->bigFrame;
 	const int lights = S.nLights > 0 ? S.nLights : 1;
 
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
@@ -1903,6 +2547,8 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		// every traversal running at the same time needs its own stack-overflow strip
 		Work Wx = W;
 		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + k % RT_AUX_STREAMS ) * W.spillStride * RT_SPILL_CAP;
+		Wx.coopLive = c->coopShadow ? (uint32_t) c->coopLive : 0u;
+		Wx.coopCap = (uint32_t) c->coopCap;
 
 		// a persistent grid never needs more waves than there are chunks
 		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
@@ -1917,7 +2563,10 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		void ( *closest )( DevScene, Work, int, int ) = big
 			? ( stats ? k_closest<true, RT_WAVES_CLOSEST_BIG> : k_closest<false, RT_WAVES_CLOSEST_BIG> )
 			: ( stats ? k_closest<true, RT_WAVES_CLOSEST> : k_closest<false, RT_WAVES_CLOSEST> );
-		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, W, k, ids ? 1 : 0 );
+		Work Wc = W;
+		Wc.coopLive = c->coopClosest ? (uint32_t) c->coopLive : 0u;
+		Wc.coopCap = (uint32_t) c->coopCap;
+		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, Wc, k, ids ? 1 : 0 );
 		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
 		if ( overlap )
 		{
@@ -1956,6 +2605,17 @@ int rt_hip_sync( rt_hip_ctx *c )
 	return 0;
 }
 
+// after a synchronisation: did any list append of the last frame run out of room?
+static int check_overflow( rt_hip_ctx *c )
+{
+	uint32_t ov = 0;
+	HIPCHK( hipMemcpyAsync( &ov, (char *) c->ctr.p + offsetof( Counters, overflow ), sizeof( ov ), hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	if ( ov )
+		return fail( "the last frame overflowed work list %u (1 hits, 2 rays; capacity %u entries): the image is incomplete", ov, c->W.cap );
+	return 0;
+}
+
 int rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host )
 {
 	if ( !c || !host ) return fail( "rt_hip_read_frame: bad arguments" );
@@ -1963,7 +2623,7 @@ int rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host )
 	if ( !c->frame.p ) return fail( "rt_hip_read_frame: nothing rendered" );
 	HIPCHK( hipMemcpyAsync( host, c->frame.p, sizeof( rt_argb ) * (size_t) c->W.npix, hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
-	return 0;
+	return check_overflow( c );
 }
 
 void *rt_hip_alloc_host( rt_hip_ctx *c, size_t bytes )
@@ -2017,6 +2677,10 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 	Counters h;
 	HIPCHK( hipMemcpyAsync( &h, c->ctr.p, sizeof( h ), hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
+	if ( h.overflow )
+		return fail( "the last frame overflowed work list %u (1 hits, 2 rays; capacity %u entries): the counters are incomplete; rays %u %u %u %u, hits %u %u %u %u %u", h.overflow, c->W.cap,
+			h.rayCount[1].v, h.rayCount[2].v, h.rayCount[3].v, h.rayCount[4].v,
+			h.hitCount[0].v, h.hitCount[1].v, h.hitCount[2].v, h.hitCount[3].v, h.hitCount[4].v );
 	memset( out, 0, sizeof( *out ) );
 	out->raysClosest = c->validPixels;
 	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.validRays[k];

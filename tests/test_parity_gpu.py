@@ -14,8 +14,9 @@ from oracle import orc
 from oracle.gen_golden import image_scenes
 from raytracing_amd import scenes
 from raytracing_amd import types as T
-from raytracing_amd.pipe import (RT_HIP_HITIDS, RT_HIP_STATS, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
-                                 RT_PARAM_STACK_SIZE, RT_PARAM_TREE_CACHE, FlatTree, HipRenderer, RenderPipe)
+from raytracing_amd.pipe import (RT_HIP_HITIDS, RT_HIP_STATS, RT_PARAM_COOP_LIVE, RT_PARAM_COOP_STACK, RT_PARAM_MAX_DEPTH,
+                                 RT_PARAM_MAX_PRIMS_IN_NODE, RT_PARAM_STACK_SIZE, RT_PARAM_TREE_CACHE, FlatTree, HipRenderer,
+                                 RenderPipe)
 from tests import known_answers
 from tests.helpers import GOLD, random_soup
 
@@ -24,13 +25,15 @@ pytestmark = pytest.mark.gpu
 IMG = image_scenes()
 
 
-def hip_render(sc, depth=10, prims=7, flags=RT_HIP_HITIDS | RT_HIP_STATS, tile=None):
+def hip_render(sc, depth=10, prims=7, flags=RT_HIP_HITIDS | RT_HIP_STATS, tile=None, params=()):
     v, t = sc.flatten()
     tree = FlatTree.build(v, t, depth, prims)
     r = HipRenderer(0)
     r.load_scene(sc, tree)
     if tile:
         r.set_tile(*tile)
+    for key, value in params:
+        r.set_param(key, value)
     r.render(flags)
     img, ids, st = r.read_frame(), r.read_hit_ids(), r.stats()
     r.close()
@@ -99,11 +102,12 @@ def test_fixture_scenes_match_committed_vectors(name):
     img, ids, st, _ = hip_render(sc, depth, prims)
     same, exact = assert_parity(img, ids, z["img"], z["hit"])
     assert same == 1.0 and exact == 1.0
-    # same rays and hits as the restatement; shadow queries may stop early
-    # (they are cut at the light and at full opacity), never do more work
+    # same rays and hits as the restatement.  The work differs both ways: queries skip the cells
+    # behind the ray origin and beyond the light and stop at full opacity; rays walked
+    # cooperatively scan the leaves behind the one that ends them.  Bounded, not equal.
     zs = dict(zip(("raysClosest", "raysShadow", "nodeVisits", "triTests", "hits"), z["stats"].tolist()))
     assert [st[k] for k in ("raysClosest", "raysShadow", "hits")] == [zs[k] for k in ("raysClosest", "raysShadow", "hits")]
-    assert st["nodeVisits"] <= zs["nodeVisits"] and st["triTests"] <= zs["triTests"]
+    assert st["nodeVisits"] <= 1.5 * zs["nodeVisits"] and st["triTests"] <= 1.5 * zs["triTests"]
 
 
 @pytest.mark.parametrize("seed,depth", [(1, 10), (2, 18), (3, 26)])
@@ -127,11 +131,65 @@ def test_random_soup_with_spheres_and_two_lights(seed, depth):
     same, exact = assert_parity(img, ids, oimg, oid)
     assert same == 1.0 and exact >= 0.999
     assert st["raysClosest"] == ost["raysClosest"] and st["raysShadow"] == ost["raysShadow"]
-    # never more traversal work than the restatement (cells behind the ray
-    # origin and beyond the light are skipped)
-    assert st["triTests"] - st["triTestsShadow"] <= ost["triTests"] - ost["triTestsShadow"]
-    assert st["nodeVisits"] - st["nodeVisitsShadow"] <= ost["nodeVisits"] - ost["nodeVisitsShadow"]
-    assert st["triTestsShadow"] <= ost["triTestsShadow"] and st["nodeVisitsShadow"] <= ost["nodeVisitsShadow"]
+    # traversal work of the same order as the restatement's (cells behind the ray origin and
+    # beyond the light are skipped; cooperative walks scan some leaves in vain)
+    assert st["triTests"] - st["triTestsShadow"] <= 2 * (ost["triTests"] - ost["triTestsShadow"])
+    assert st["nodeVisits"] - st["nodeVisitsShadow"] <= 2 * (ost["nodeVisits"] - ost["nodeVisitsShadow"])
+    assert st["triTestsShadow"] <= 2 * ost["triTestsShadow"] and st["nodeVisitsShadow"] <= 2 * ost["nodeVisitsShadow"]
+
+
+def _coop_scene(kind):
+    if kind == "glass":
+        return IMG["sphere16k_glass"]
+    if kind == "wavy_deep":
+        return IMG["wavy32_deep"]
+    if kind == "default":
+        return IMG["default_small"]
+    if kind == "soup_negative_alpha":
+        return _soup_scene(11, 3000, (1.0, -0.5, 0.7)), 14, 6
+    if kind == "big_leaves":
+        return _soup_scene(12, 700, (1.0, 0.6, 1.0), w=96, h=64), 3, 7
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["glass", "wavy_deep", "default", "soup_negative_alpha", "big_leaves"])
+def test_cooperative_walk_gives_the_lane_per_ray_image(kind):
+    """A wave whose rays have thinned out lets the remaining rays share its lanes
+    (several leaves of a ray per round, sub-trees descended side by side).  Where
+    that sets in (RT_PARAM_COOP_LIVE: never, at 4 rays, at 32) and how much stack
+    it may use (RT_PARAM_COOP_STACK: 12 entries, 2, none - then every round
+    restarts the walk at the root) must not change a bit of the result, closest
+    hits and shadow sums (with negative opacities: no early exit) alike."""
+    sc, depth, prims = _coop_scene(kind)
+    want = None
+    for live, stack in [(0, 12), (4, 12), (32, 12), (32, 2), (32, 0), (9, 1)]:
+        img, ids, st, tree = hip_render(sc, depth, prims, params=((RT_PARAM_COOP_LIVE, live), (RT_PARAM_COOP_STACK, stack)))
+        if want is None:
+            nodes, idx = tree.expand()
+            oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+            assert np.array_equal(ids, oid) and np.abs(img.astype(int) - oimg.astype(int)).max() <= 1
+            want = (img, ids, st)
+        assert np.array_equal(img, want[0]) and np.array_equal(ids, want[1]), (live, stack)
+        assert [st[k] for k in ("raysClosest", "raysShadow", "hits")] == [want[2][k] for k in ("raysClosest", "raysShadow", "hits")]
+        tree.release()
+
+
+def test_short_ray_lists_are_spread_over_the_chip():
+    """Lists too short to give every resident wave 64 rays are dealt out in
+    smaller chunks and walked cooperatively from the first round: a 1080p frame
+    of a mirror-in-mirror scene has such lists in its deep slots.  Lattice check
+    against the oracle and equality with the lane-per-ray walk."""
+    sc = scenes.sphere_scene(250, 200, 1920, 1080, reflect=0.5, stack_size=6)
+    a = hip_render(sc, 22, 8, flags=RT_HIP_HITIDS)
+    b = hip_render(sc, 22, 8, flags=RT_HIP_HITIDS, params=((RT_PARAM_COOP_LIVE, 0),))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2]["slotRays"] == b[2]["slotRays"] and 0 < a[2]["slotRays"][5] < 200000
+    nodes, idx = a[3].expand()
+    oimg, oid, _ = orc.raytrace(sc, a[3].bbox, nodes, idx, x0=3, x_step=8, y0=1, y_step=8)
+    m = np.zeros(a[1].shape, bool)
+    m[1::8, 3::8] = True
+    same, exact = assert_parity(a[0], a[1], oimg, oid, m)
+    assert same == 1.0 and exact == 1.0
 
 
 def test_render_pipe_api_matches_and_consumes_the_scene():
