@@ -137,6 +137,13 @@ struct Counters
 	Ctr headShade[RT_MAX_SLOTS];          // chunk dispenser of k_light
 	Ctr headShadow[RT_MAX_SLOTS];         // chunk dispenser of k_shadow
 	uint32_t overflow;                    // a list append did not fit its buffer (host reports an error)
+#ifdef RT_PROFILE_CHUNKS
+	// development build: per slot, histogram of chunk durations (10 us bins) and wave-level round counts
+	uint32_t chunkHist[RT_MAX_SLOTS][64];
+	unsigned long long lockRounds[RT_MAX_SLOTS], coopRounds[RT_MAX_SLOTS], coopIters[RT_MAX_SLOTS], chunksSeen[RT_MAX_SLOTS];
+	unsigned long long tExpand[RT_MAX_SLOTS], tScan[RT_MAX_SLOTS], tCoop[RT_MAX_SLOTS], tChunk[RT_MAX_SLOTS];
+	uint32_t maxLock[RT_MAX_SLOTS], maxCoop[RT_MAX_SLOTS], maxIters[RT_MAX_SLOTS];
+#endif
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
 	unsigned long long nodeSlots, triSlots, nodeSlotsShadow, triSlotsShadow;   // lane-slots spent (STATS)
@@ -745,6 +752,20 @@ DEVI void alpha_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, float
 #define RT_COOP_POP 64u       // sub-trees a segment takes off the stack at a time (at most its free lanes)
 #endif
 
+#ifdef RT_PROFILE_CHUNKS
+struct Prof { uint32_t lock, coop, iters; unsigned long long tExpand, tScan, tCoop; };
+#define PROF_T0( v ) const unsigned long long v = wall_clock64()
+#define PROF_ADD( f, v ) ( pf.f += wall_clock64() - v )
+#define PROF_ARG , Prof &pf
+#define PROF_PASS , pf
+#define PROF_INC( x ) ( ++pf.x )
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_INC( x ) ( (void) 0 )
+#define PROF_T0( v ) ( (void) 0 )
+#define PROF_ADD( f, v ) ( (void) 0 )
+#endif
 // exchange area of the expand step: 5 words per lane, [word * RT_BLOCK + thread]
 __shared__ uint32_t g_lds_xch[5 * RT_BLOCK];
 // rank -> lane of the rays still walking, one table per wave
@@ -791,7 +812,7 @@ struct SegEntry { uint32_t cur, nx, ny; float tN, tF; };
 // lost = the stack did not fit (its content is void, the ray restarts).
 template <bool STATS>
 DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn, float T, float tEnd, bool restart, uint32_t col, uint32_t cap,
-	SegEntry &en, bool &have, uint32_t &sp, bool &lost, Tally &tl )
+	SegEntry &en, bool &have, uint32_t &sp, bool &lost, Tally &tl PROF_ARG )
 {
 	uint32_t *const xw = g_lds_xch + threadIdx.x;                  // my own slot
 	uint32_t *const xs = g_lds_xch + ( threadIdx.x - g.j );         // slot 0 of my segment
@@ -835,6 +856,7 @@ DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn
 		}
 		if ( __ballot( segInner || take != 0u ) == 0ull )
 			break;
+		PROF_INC( iters );
 		// exit distance of the entry before me (entry distance of a sub-tree that joins behind it)
 		const float prevF = shfl_f( en.tF, ( g.start + ( kept ? kept - 1u : 0u ) ) & 63u );
 		if ( segInner )
@@ -933,7 +955,7 @@ DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn
 // [t.tNear, t.tFar] with t.sp entries on its stack; h carries the persistent
 // part of the hit state in and the result out.  Wave-uniform.
 template <bool STATS>
-DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav &t, NearHit &h, Tally &tl, uint32_t cap )
+DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav &t, NearHit &h, Tally &tl, uint32_t cap PROF_ARG )
 {
 	uint32_t *const own = g_lds_owner + ( threadIdx.x & ~63u );
 	// from here on a ray is (entry distance T, stack): the node the lane was about
@@ -958,6 +980,7 @@ DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav
 		if ( mA == 0ull )
 			break;
 		const uint32_t nA = (uint32_t) __popcll( mA );
+		PROF_INC( coop );
 		const uint32_t lq = 31u - (uint32_t) __clz( (int) ( 64u / nA ) ), q = 1u << lq;
 		const Seg g = make_seg( q );
 		// segment s belongs to the s-th walking ray
@@ -985,7 +1008,10 @@ DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav
 
 		SegEntry en;
 		bool have, lost;
-		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl );
+		PROF_T0( pe );
+		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl PROF_PASS );
+		PROF_ADD( tExpand, pe );
+		PROF_T0( ps );
 
 		// scan: my leaf, CL/rt_funcs_primitives.cl:74-111
 		const TriRay R = tri_ray( sr.src, sr.dest );
@@ -1008,6 +1034,7 @@ DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav
 			}
 		}
 
+		PROF_ADD( tScan, ps );
 		// resolve, by the lane that owns the ray: the leaves of its segment in
 		// order (:168-183).  The first leaf with a hit before its exit distance
 		// ends the ray; otherwise the last leaf with any hit leaves its triangle
@@ -1056,7 +1083,7 @@ DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav
 // have hits.  In: the lane is about to open node t.cur over [t.tNear, t.tFar]
 // with t.sp entries on its stack, alpha = the sum so far.
 template <bool STATS>
-DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &t, float d, float &alpha, Tally &tl, uint32_t cap )
+DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &t, float d, float &alpha, Tally &tl, uint32_t cap PROF_ARG )
 {
 	uint32_t *const own = g_lds_owner + ( threadIdx.x & ~63u );
 	uint32_t sp = 0u;
@@ -1082,6 +1109,7 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 		if ( mA == 0ull )
 			break;
 		const uint32_t nA = (uint32_t) __popcll( mA );
+		PROF_INC( coop );
 		const uint32_t lq = 31u - (uint32_t) __clz( (int) ( 64u / nA ) ), q = 1u << lq;
 		const Seg g = make_seg( q );
 		const uint32_t rank = lanes_below( mA );
@@ -1111,7 +1139,7 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 
 		SegEntry en;
 		bool have, lost;
-		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl );
+		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl PROF_PASS );
 
 		// scan: the hits of my leaf that count, in triangle order; the first two
 		// opacities are kept, a leaf with more is scanned again when its turn comes
@@ -1195,7 +1223,7 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 // keep their own lane.
 template <bool STATS>
 DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl,
-	uint32_t coopLive, uint32_t coopCap, bool atOnce )
+	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	const bool mayCoop = coopLive != 0u && !axis_parallel( r );
@@ -1204,11 +1232,14 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 	{
 		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && mayCoop ) != 0ull )
 		{
-			nearest_coop<STATS>( S, r, live && mayCoop, t, h, tl, coopCap );
+			PROF_T0( pc );
+			nearest_coop<STATS>( S, r, live && mayCoop, t, h, tl, coopCap PROF_PASS );
+			PROF_ADD( tCoop, pc );
 			live = live && !mayCoop;
 			continue;
 		}
 		walked = true;
+		PROF_INC( lock );
 		float lt = INFINITY;
 		uint32_t cnt = 0u;
 		if ( live )
@@ -1254,7 +1285,7 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 // shadow query of every lane with `live` set, CL/rt_funcs_primitives.cl:295-378
 template <bool STATS>
 DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, float d, float &alpha, Tally &tl,
-	uint32_t coopLive, uint32_t coopCap, bool atOnce )
+	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	const bool mayCoop = coopLive != 0u && !axis_parallel( r );
@@ -1263,11 +1294,12 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 	{
 		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && mayCoop ) != 0ull )
 		{
-			alpha_coop<STATS>( S, r, live && mayCoop, t, d, alpha, tl, coopCap );
+			alpha_coop<STATS>( S, r, live && mayCoop, t, d, alpha, tl, coopCap PROF_PASS );
 			live = live && !mayCoop;
 			continue;
 		}
 		walked = true;
+		PROF_INC( lock );
 		uint32_t cnt = 0u;
 		if ( live )
 		{
@@ -1678,7 +1710,8 @@ DEVI uint32_t chunk_shift( uint32_t count, uint32_t coopLive )
 	uint32_t shift = 6u;
 	if ( coopLive != 0u )
 	{
-		const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
+		// (bits 8..15 of coopLive: development knob, waves wanted per resident wave in eighths)
+		const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u ) * ( ( coopLive >> 8 ) & 0xffu ) / 8u;
 		while ( shift > RT_COOP_MIN_SHIFT && ( ( count + ( 1u << shift ) - 1u ) >> shift ) < waves ) --shift;
 	}
 	return shift;
@@ -1691,7 +1724,7 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
 
 	const uint32_t count = ray_list_count( W, slot );
-	const uint32_t shift = slot == 0 ? 6u : chunk_shift( count, W.coopLive );   // slot 0 is dealt out in 8x8 pixel tiles
+	const uint32_t shift = chunk_shift( count, W.coopLive );
 	uint32_t first;
 	Grab grab = { 0u };
 	ClosestOut out = {};
@@ -1717,8 +1750,30 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 			// halves the speed on this workload: it destroys exactly that locality.)
 			live = trav_begin<STATS>( S, rh.ray, t, tl );
 		}
-		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive, W.coopCap, shift < 6u );
+#ifdef RT_PROFILE_CHUNKS
+		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull };
+		const unsigned long long c0 = wall_clock64();
+#endif
+		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
 		finish_closest( S, W, slot, wantIds, out, valid, e, rh, h, sph );
+#ifdef RT_PROFILE_CHUNKS
+		if ( lane_id() == 0u )
+		{
+			const unsigned long long dt = ( wall_clock64() - c0 ) / 1000ull;       // 100 MHz ticks -> 10 us
+			atomicAdd( &W.ctr->chunkHist[slot][dt < 63ull ? dt : 63ull], 1u );
+			atomicAdd( &W.ctr->lockRounds[slot], (unsigned long long) pf.lock );
+			atomicAdd( &W.ctr->coopRounds[slot], (unsigned long long) pf.coop );
+			atomicAdd( &W.ctr->coopIters[slot], (unsigned long long) pf.iters );
+			atomicAdd( &W.ctr->chunksSeen[slot], 1ull );
+			atomicAdd( &W.ctr->tExpand[slot], pf.tExpand );
+			atomicAdd( &W.ctr->tScan[slot], pf.tScan );
+			atomicAdd( &W.ctr->tCoop[slot], pf.tCoop );
+			atomicAdd( &W.ctr->tChunk[slot], wall_clock64() - c0 );
+			atomicMax( &W.ctr->maxLock[slot], pf.lock );
+			atomicMax( &W.ctr->maxCoop[slot], pf.coop );
+			atomicMax( &W.ctr->maxIters[slot], pf.iters );
+		}
+#endif
 	}
 	closest_out_close( W, slot, out );
 	if ( STATS )
@@ -1806,7 +1861,10 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScen
 				}
 			}
 		}
-		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive, W.coopCap, shift < 6u );
+#ifdef RT_PROFILE_CHUNKS
+		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull };
+#endif
+		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
 		if ( item )
 			W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
@@ -2014,7 +2072,7 @@ struct rt_hip_ctx
 	bool workDirty = true;
 	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
 	int gridShadow[2] = { 0, 0 }, gridLight = 0;
-	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK;
+	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK, coopFill = 8, coopAtOnce = 0;
 	uint32_t bigFrame = RT_BIG_FRAME;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[RT_AUX_STREAMS] = {};        // shadow + lighting passes (slot k on stream k mod RT_AUX_STREAMS)
@@ -2127,6 +2185,8 @@ rt_hip_ctx *rt_hip_create( int device )
 	// development knob
 	if ( const char *v = getenv( "RT_COOP_LIVE" ) ) c->coopLive = atoi( v );
 	if ( c->coopLive < 0 || c->coopLive > 32 ) c->coopLive = 0;
+	if ( const char *v = getenv( "RT_COOP_FILL" ) ) c->coopFill = atoi( v ) > 0 && atoi( v ) < 256 ? atoi( v ) : 8;
+	if ( const char *v = getenv( "RT_COOP_ATONCE" ) ) c->coopAtOnce = atoi( v );
 	if ( const char *v = getenv( "RT_COOP_SHADOW" ) ) c->coopShadow = atoi( v );
 	if ( const char *v = getenv( "RT_COOP_CLOSEST" ) ) c->coopClosest = atoi( v );
 	if ( const char *v = getenv( "RT_BIG_FRAME" ) ) c->bigFrame = (uint32_t) atoll( v );
@@ -2547,7 +2607,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		// every traversal running at the same time needs its own stack-overflow strip
 		Work Wx = W;
 		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + k % RT_AUX_STREAMS ) * W.spillStride * RT_SPILL_CAP;
-		Wx.coopLive = c->coopShadow ? (uint32_t) c->coopLive : 0u;
+		Wx.coopLive = c->coopShadow && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wx.coopCap = (uint32_t) c->coopCap;
 
 		// a persistent grid never needs more waves than there are chunks
@@ -2564,7 +2624,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 			? ( stats ? k_closest<true, RT_WAVES_CLOSEST_BIG> : k_closest<false, RT_WAVES_CLOSEST_BIG> )
 			: ( stats ? k_closest<true, RT_WAVES_CLOSEST> : k_closest<false, RT_WAVES_CLOSEST> );
 		Work Wc = W;
-		Wc.coopLive = c->coopClosest ? (uint32_t) c->coopLive : 0u;
+		Wc.coopLive = c->coopClosest && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wc.coopCap = (uint32_t) c->coopCap;
 		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, Wc, k, ids ? 1 : 0 );
 		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
@@ -2681,6 +2741,19 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 		return fail( "the last frame overflowed work list %u (1 hits, 2 rays; capacity %u entries): the counters are incomplete; rays %u %u %u %u, hits %u %u %u %u %u", h.overflow, c->W.cap,
 			h.rayCount[1].v, h.rayCount[2].v, h.rayCount[3].v, h.rayCount[4].v,
 			h.hitCount[0].v, h.hitCount[1].v, h.hitCount[2].v, h.hitCount[3].v, h.hitCount[4].v );
+#ifdef RT_PROFILE_CHUNKS
+	for ( int k = 0; k < c->S.stackSize; ++k )
+	{
+		fprintf( stderr, "[prof] slot %d: %llu chunks, per chunk %.1f lane-per-ray rounds (max %u), %.1f cooperative rounds (max %u), %.1f expand steps (max %u); duration histogram (10 us bins):",
+			k, h.chunksSeen[k], (double) h.lockRounds[k] / ( h.chunksSeen[k] ? h.chunksSeen[k] : 1 ), h.maxLock[k],
+			(double) h.coopRounds[k] / ( h.chunksSeen[k] ? h.chunksSeen[k] : 1 ), h.maxCoop[k],
+			(double) h.coopIters[k] / ( h.chunksSeen[k] ? h.chunksSeen[k] : 1 ), h.maxIters[k] );
+		const double n = h.chunksSeen[k] ? (double) h.chunksSeen[k] : 1.0;
+		fprintf( stderr, " [us per chunk: total %.1f, cooperative %.1f of which expand %.1f scan %.1f]", h.tChunk[k] / n / 100.0, h.tCoop[k] / n / 100.0, h.tExpand[k] / n / 100.0, h.tScan[k] / n / 100.0 );
+		if ( getenv( "RT_PROF_HIST" ) ) for ( int b = 0; b < 64; ++b ) if ( h.chunkHist[k][b] ) fprintf( stderr, " %d:%u", b, h.chunkHist[k][b] );
+		fprintf( stderr, "\n" );
+	}
+#endif
 	memset( out, 0, sizeof( *out ) );
 	out->raysClosest = c->validPixels;
 	for ( int k = 1; k < RT_MAX_SLOTS; ++k ) out->raysClosest += h.validRays[k];

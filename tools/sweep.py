@@ -19,7 +19,7 @@ def main():
         tb = time.time() - t0
         r.load_scene(sc, tree)
         if os.environ.get("RT_PARTS"):
-            r.set_tile(16, int(os.environ["RT_PARTS"]), 0)
+            r.set_tile(int(os.environ.get("RT_BAND", "16")), int(os.environ["RT_PARTS"]), int(os.environ.get("RT_PART", "0")))
         if os.environ.get("RT_OVERLAP") is not None:
             r.set_param(RT_PARAM_OVERLAP, int(os.environ["RT_OVERLAP"]))
         best = None
