@@ -60,6 +60,9 @@
 #ifndef RT_WAVES_CLOSEST
 #define RT_WAVES_CLOSEST 4
 #endif
+#ifndef RT_WAVES_CLOSEST_STATS
+#define RT_WAVES_CLOSEST_STATS 3     // the counting build needs more registers
+#endif
 #ifndef RT_WAVES_CLOSEST_BIG
 #define RT_WAVES_CLOSEST_BIG RT_WAVES_CLOSEST
 #endif
@@ -1220,23 +1223,24 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 // coopLive: once at most that many lanes are still walking (and at least one
 // round has been walked, or `atOnce`), the rest of the rays is walked
 // cooperatively (nearest_coop); 0 = never.  Rays parallel to an axis always
-// keep their own lane.
+// keep their own lane, and the gear change waits for them.
 template <bool STATS>
 DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl,
 	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	const bool mayCoop = coopLive != 0u && !axis_parallel( r );
+	// the cooperative walk is the last thing a chunk does (nothing of the lane-per-ray
+	// walk stays live across it): rays parallel to an axis are finished first
+	const bool ownLane = coopLive == 0u || axis_parallel( r );
 	bool walked = atOnce;
 	while ( __ballot( live ) != 0ull )
 	{
-		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && mayCoop ) != 0ull )
+		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && ownLane ) == 0ull )
 		{
 			PROF_T0( pc );
-			nearest_coop<STATS>( S, r, live && mayCoop, t, h, tl, coopCap PROF_PASS );
+			nearest_coop<STATS>( S, r, live, t, h, tl, coopCap PROF_PASS );
 			PROF_ADD( tCoop, pc );
-			live = live && !mayCoop;
-			continue;
+			return;
 		}
 		walked = true;
 		PROF_INC( lock );
@@ -1288,15 +1292,14 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	const bool mayCoop = coopLive != 0u && !axis_parallel( r );
+	const bool ownLane = coopLive == 0u || axis_parallel( r );
 	bool walked = atOnce;
 	while ( __ballot( live ) != 0ull )
 	{
-		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && mayCoop ) != 0ull )
+		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && ownLane ) == 0ull )
 		{
-			alpha_coop<STATS>( S, r, live && mayCoop, t, d, alpha, tl, coopCap PROF_PASS );
-			live = live && !mayCoop;
-			continue;
+			alpha_coop<STATS>( S, r, live, t, d, alpha, tl, coopCap PROF_PASS );
+			return;
 		}
 		walked = true;
 		PROF_INC( lock );
@@ -2166,8 +2169,8 @@ rt_hip_ctx *rt_hip_create( int device )
 	// persistent grids: one resident wave set per CU, as many blocks as fit
 	int occ = 0;
 	struct { const void *f; int *dst; int *occ; } ks[7] = {
-		{ (const void *) k_closest<false, RT_WAVES_CLOSEST>, &c->gridClosest[0][0], nullptr }, { (const void *) k_closest<true, RT_WAVES_CLOSEST>, &c->gridClosest[0][1], nullptr },
-		{ (const void *) k_closest<false, RT_WAVES_CLOSEST_BIG>, &c->gridClosest[1][0], nullptr }, { (const void *) k_closest<true, RT_WAVES_CLOSEST_BIG>, &c->gridClosest[1][1], nullptr },
+		{ (const void *) k_closest<false, RT_WAVES_CLOSEST>, &c->gridClosest[0][0], nullptr }, { (const void *) k_closest<true, RT_WAVES_CLOSEST_STATS>, &c->gridClosest[0][1], nullptr },
+		{ (const void *) k_closest<false, RT_WAVES_CLOSEST_BIG>, &c->gridClosest[1][0], nullptr }, { (const void *) k_closest<true, RT_WAVES_CLOSEST_STATS>, &c->gridClosest[1][1], nullptr },
 		{ (const void *) k_shadow<false>, &c->gridShadow[0], &c->occShadow[0] }, { (const void *) k_shadow<true>, &c->gridShadow[1], &c->occShadow[1] },
 		{ (const void *) k_light, &c->gridLight, nullptr } };
 	for ( auto &k : ks )
@@ -2621,8 +2624,8 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 
 		if ( timing ) HIPCHK( hipEventRecord( e[0], s ) );
 		void ( *closest )( DevScene, Work, int, int ) = big
-			? ( stats ? k_closest<true, RT_WAVES_CLOSEST_BIG> : k_closest<false, RT_WAVES_CLOSEST_BIG> )
-			: ( stats ? k_closest<true, RT_WAVES_CLOSEST> : k_closest<false, RT_WAVES_CLOSEST> );
+			? ( stats ? k_closest<true, RT_WAVES_CLOSEST_STATS> : k_closest<false, RT_WAVES_CLOSEST_BIG> )
+			: ( stats ? k_closest<true, RT_WAVES_CLOSEST_STATS> : k_closest<false, RT_WAVES_CLOSEST> );
 		Work Wc = W;
 		Wc.coopLive = c->coopClosest && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wc.coopCap = (uint32_t) c->coopCap;

@@ -72,3 +72,27 @@ def test_library_exports_every_declared_symbol():
 def test_hbm_record_sizes():
     from raytracing_amd import pipe
     assert pipe.kdnode.itemsize == 8 and pipe.trirec.itemsize == 48 and pipe.trishade.itemsize == 48
+
+
+def test_frame_kernels_keep_their_state_in_registers(tmp_path):
+    """No kernel of a frame may spill registers to scratch memory: spill traffic
+    is HBM traffic in the hottest loops, and builds of the traversal kernels
+    that spilled heavily have produced wrong pixels.  Read from the metadata
+    of the device code inside the built library."""
+    import shutil
+    import subprocess
+    import pytest
+    from raytracing_amd._lib import SO
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{tools}/llvm-objdump") and os.path.exists(f"{tools}/llvm-readelf")):
+        pytest.skip("LLVM binary tools not installed")
+    so = shutil.copy(SO, tmp_path / "lib.so")
+    subprocess.run([f"{tools}/llvm-objdump", "--offloading", so], check=True, capture_output=True, cwd=tmp_path)
+    seen = {}
+    for obj in sorted(tmp_path.glob("lib.so.*gfx950*")):
+        notes = subprocess.run([f"{tools}/llvm-readelf", "--notes", str(obj)], check=True, capture_output=True, text=True).stdout
+        for name, scratch in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            seen[name] = int(scratch)
+    frame = {k: v for k, v in seen.items() if re.search(r"k_closest|k_shadow|k_light|k_fold", k)}
+    assert len(frame) >= 6, sorted(seen)
+    assert all(v == 0 for v in frame.values()), frame

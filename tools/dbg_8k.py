@@ -7,9 +7,13 @@ from oracle import orc
 
 w, h, step = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 flags = int(sys.argv[4]) if len(sys.argv) > 4 else (RT_HIP_STATS | RT_HIP_HITIDS)
-sc = scenes.sphere_scene(250, 200, w, h, reflect=0.5, stack_size=5)
+import os
+if os.environ.get("SCENE") == "config3":
+    sc = scenes.config3(w, h)
+else:
+    sc = scenes.sphere_scene(250, 200, w, h, reflect=0.5, stack_size=5)
 v, t = sc.flatten()
-tree = FlatTree.build(v, t, 24, 12)
+tree = FlatTree.build(v, t, int(os.environ.get("DEPTH", "24")), int(os.environ.get("LEAF", "12")))
 nodes, idx = tree.expand()
 import os
 for rep in range(int(os.environ.get('REPS', '2'))):
