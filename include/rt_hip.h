@@ -150,6 +150,27 @@ int  rt_hip_set_param( rt_hip_ctx *c, int key, int value );
  * own frame buffer.  Asynchronous.
  */
 int  rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags );
+/*
+ * The same frame without a single allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate - code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The per-frame
+ * work buffers come from one fixed array in device memory (RT_HIP_NOALLOC_BYTES,
+ * held by every GPU the library runs on until the process ends) instead of
+ * buffers sized for the image, hence the limits: at most
+ * RT_HIP_NOALLOC_MAX_PIXELS pixels in this context's share of the image,
+ * RT_HIP_NOALLOC_MAX_SLOTS rays per pixel and RT_HIP_NOALLOC_MAX_LIGHTS lights;
+ * anything beyond is refused with an error.  d_out (device, w *
+ * rt_hip_local_rows() rt_argb) is required, flags must be 0, tree / materials /
+ * spheres / lights must have been uploaded (empty tables included), passes run
+ * in order on the context's stream.  Every call on a GPU uses that GPU's one
+ * array: calls that overlap in time on one GPU (two contexts, two streams) race.
+ * Same pixels as rt_hip_render.
+ */
+#define RT_HIP_NOALLOC_MAX_PIXELS 65536
+#define RT_HIP_NOALLOC_MAX_SLOTS  6
+#define RT_HIP_NOALLOC_MAX_LIGHTS 4
+#define RT_HIP_NOALLOC_BYTES      ( 96u << 20 )
+int  rt_hip_render_noalloc( rt_hip_ctx *c, void *d_out, unsigned flags );
 int  rt_hip_sync( rt_hip_ctx *c );
 int  rt_hip_read_frame( rt_hip_ctx *c, rt_argb *host );        /* internal frame buffer -> host, synchronous */
 int  rt_hip_read_hit_ids( rt_hip_ctx *c, int32_t *host );      /* after RT_HIP_HITIDS */

@@ -2132,6 +2132,7 @@ static int upload( rt_hip_ctx *c, DevBuf &b, const void *src, size_t bytes )
 }
 
 void rt_hip_destroy( rt_hip_ctx *c );
+static int scratch_lookup( int device );      // device address of the allocation-free entry point's work area
 
 rt_hip_ctx *rt_hip_create( int device )
 {
@@ -2157,6 +2158,12 @@ rt_hip_ctx *rt_hip_create( int device )
 	}
 	c->numCU = prop.multiProcessorCount;
 	c->stream = c->own;
+	// this GPU's address of the allocation-free entry point's work area
+	if ( scratch_lookup( device ) )
+	{
+		rt_hip_destroy( c );
+		return nullptr;
+	}
 	memset( &c->S, 0, sizeof( c->S ) );
 	memset( &c->W, 0, sizeof( c->W ) );
 	c->S.stackSize = STACK_SIZE;
@@ -2562,6 +2569,8 @@ static int prepare_work( rt_hip_ctx *c )
 	return 0;
 }
 
+static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned flags, bool overlap, int gridCap );
+
 int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 {
 	if ( !c ) return fail( "null context" );
@@ -2577,10 +2586,16 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	if ( (unsigned long long) list_capacity( c, (size_t) c->S.w * c->S.localH ) * (unsigned long long) ( c->S.nLights > 0 ? c->S.nLights : 1 ) >= ( 1ull << 31 ) )
 		return fail( "rt_hip_render: pixels x lights exceeds the 31-bit work-item range" );
 	if ( ( c->workDirty || c->workLights != c->S.nLights ) && prepare_work( c ) ) return 1;
+	return enqueue_frame( c, c->W, d_out ? (rt_argb *) d_out : (rt_argb *) c->frame.p, flags, c->overlap && c->S.stackSize > 1, 0 );
+}
+
+// The launches of one frame over the work buffers `W` (see the top of this
+// file).  gridCap > 0 limits every persistent grid to that many workgroups.
+// Allocates nothing unless RT_HIP_TIMING asks for events that do not exist yet.
+static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned flags, bool overlap, int gridCap )
+{
 	const bool stats = flags & RT_HIP_STATS, ids = flags & RT_HIP_HITIDS, timing = flags & RT_HIP_TIMING;
 	const DevScene &S = c->S;
-	const Work &W = c->W;
-	rt_argb *out = d_out ? (rt_argb *) d_out : (rt_argb *) c->frame.p;
 	hipStream_t s = c->stream;
 
 	if ( timing && !c->haveEvents )
@@ -2595,12 +2610,11 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	}
 	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
 	hipEvent_t *evFold = ev + 6 * RT_MAX_SLOTS, *evFrame = evFold + 2;
-	const bool overlap = c->overlap && S.stackSize > 1;
 	const bool big = W.npix >= c->bigFrame;
 	const int lights = S.nLights > 0 ? S.nLights : 1;
 
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
-	HIPCHK( hipMemsetAsync( c->ctr.p, 0, sizeof( Counters ), s ) );
+	HIPCHK( hipMemsetAsync( W.ctr, 0, sizeof( Counters ), s ) );
 	if ( W.npix == 0 )
 		return 0;
 	for ( int k = 0; k < S.stackSize; ++k )
@@ -2621,6 +2635,12 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
 		if ( k == 0 && want * (uint32_t) lights < (uint32_t) gw ) gw = (int) ( want ? want * lights : 1u );
 		if ( k == 0 && want < (uint32_t) gl ) gl = (int) ( want ? want : 1u );
+		if ( gridCap > 0 )
+		{
+			if ( gc > gridCap ) gc = gridCap;
+			if ( gw > gridCap ) gw = gridCap;
+			if ( gl > gridCap ) gl = gridCap;
+		}
 
 		if ( timing ) HIPCHK( hipEventRecord( e[0], s ) );
 		void ( *closest )( DevScene, Work, int, int ) = big
@@ -2666,6 +2686,115 @@ int rt_hip_sync( rt_hip_ctx *c )
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// rt_hip_render_noalloc: a frame without a single allocation
+//
+// Callers that cannot allocate (HIP graph capture, tight serving loops,
+// harnesses that forbid hipMalloc) get the same launches over work buffers
+// carved from one file-scope device array.  Every GPU the library runs on holds
+// its own copy of the array, at its own address, until the process ends; the
+// address is looked up once per device (rt_hip_create) and only that pointer is
+// ever handed to kernels or memsets.  All calls on one GPU share the array:
+// frames that overlap in time on one GPU race.  The counters are cleared at the
+// start of every frame; nothing else needs to start at zero (every list is
+// bounded by its own counter, every per-pixel record is written before it is
+// read).
+// ---------------------------------------------------------------------------
+#define RT_NOALLOC_GRID 128              // workgroups per persistent launch (sizes the stack-overflow strip)
+
+constexpr size_t noalloc_align( size_t x ) { return ( x + 255 ) & ~(size_t) 255; }
+struct NoallocLayout
+{
+	// entries per list: no launch here uses block reservations (they start at
+	// RT_NOALLOC_GRID * 4 * 256 = 131072 entries per list), so a list holds at most one entry per pixel
+	static constexpr size_t cap = RT_HIP_NOALLOC_MAX_PIXELS + 64;
+	static constexpr size_t npix = RT_HIP_NOALLOC_MAX_PIXELS;
+	static constexpr size_t slots = RT_HIP_NOALLOC_MAX_SLOTS, lights = RT_HIP_NOALLOC_MAX_LIGHTS;
+	static constexpr size_t oCtr = 0;
+	static constexpr size_t oRays = oCtr + noalloc_align( sizeof( Counters ) );
+	static constexpr size_t oHitA = oRays + noalloc_align( 4 * sizeof( float4 ) * cap * ( slots - 1 ) );
+	static constexpr size_t oHitB = oHitA + noalloc_align( sizeof( float4 ) * cap * slots );
+	static constexpr size_t oHitN = oHitB + noalloc_align( sizeof( uint2 ) * cap * slots );
+	static constexpr size_t oRes = oHitN + noalloc_align( sizeof( float4 ) * cap * slots );
+	static constexpr size_t oFac = oRes + noalloc_align( sizeof( float4 ) * npix * slots );
+	static constexpr size_t oShadow = oFac + noalloc_align( sizeof( float4 ) * npix * slots );
+	static constexpr size_t oStackPos = oShadow + noalloc_align( sizeof( float ) * cap * slots * lights );
+	static constexpr size_t oHitId = oStackPos + noalloc_align( sizeof( uint32_t ) * npix );
+	static constexpr size_t oSpill = oHitId + noalloc_align( sizeof( int32_t ) * npix );
+	static constexpr size_t total = oSpill + noalloc_align( sizeof( uint2 ) * (size_t) RT_NOALLOC_GRID * RT_BLOCK * RT_SPILL_CAP );
+};
+static_assert( RT_HIP_NOALLOC_MAX_SLOTS >= 2 && RT_HIP_NOALLOC_MAX_SLOTS <= RT_MAX_SLOTS, "slot limit of the allocation-free entry point" );
+static_assert( NoallocLayout::cap < (size_t) RT_NOALLOC_GRID * ( RT_BLOCK / 64 ) * RT_RESV_BLOCK, "lists must stay below the length at which reservations (holes) begin" );
+static_assert( NoallocLayout::total <= RT_HIP_NOALLOC_BYTES, "RT_HIP_NOALLOC_BYTES in rt_hip.h must cover the layout" );
+
+static __device__ __align__( 256 ) unsigned char scratch[RT_HIP_NOALLOC_BYTES];
+
+// device address of `scratch` on each GPU (the array's name is only a handle on the host)
+#define RT_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[RT_MAX_DEVICES] = {};
+
+static int scratch_lookup( int device )
+{
+	if ( device < 0 || device >= RT_MAX_DEVICES ) return fail( "device ordinal %d beyond the %d this library keeps scratch addresses for", device, RT_MAX_DEVICES );
+	if ( g_scratch_ptr[device] )
+		return 0;
+	unsigned char *p = nullptr;
+	HIPCHK( hipSetDevice( device ) );
+	HIPCHK( hipGetSymbolAddress( (void **) &p, HIP_SYMBOL( scratch ) ) );
+	if ( !p ) return fail( "hipGetSymbolAddress returned a null address for the scratch array" );
+	g_scratch_ptr[device] = p;
+	return 0;
+}
+
+int rt_hip_render_noalloc( rt_hip_ctx *c, void *d_out, unsigned flags )
+{
+	if ( !c ) return fail( "null context" );
+	if ( !d_out ) return fail( "rt_hip_render_noalloc: an output buffer is required" );
+	if ( flags != 0u ) return fail( "rt_hip_render_noalloc: flags are not supported (counting, hit ids and timing use buffers of rt_hip_render)" );
+	if ( !c->S.nodes || !c->S.mats || !c->S.spheres || !c->S.lights )
+		return fail( "rt_hip_render_noalloc: upload tree, materials, spheres and lights first (empty tables included)" );
+	if ( ( c->nRecs && c->maxMatTree >= c->nMats ) || ( c->S.nSpheres && c->maxMatSphere >= c->nMats ) )
+		return fail( "rt_hip_render_noalloc: geometry references a material slot beyond the uploaded table" );
+	const DevScene &S = c->S;
+	if ( S.w < 2 || S.h < 2 ) return fail( "rt_hip_render_noalloc: image size not set" );
+	const size_t npix = (size_t) S.w * (size_t) S.localH;
+	if ( npix > RT_HIP_NOALLOC_MAX_PIXELS )
+		return fail( "rt_hip_render_noalloc: %zu pixels exceed the limit of %d (use rt_hip_render, or render in tiles)", npix, RT_HIP_NOALLOC_MAX_PIXELS );
+	if ( S.stackSize > RT_HIP_NOALLOC_MAX_SLOTS )
+		return fail( "rt_hip_render_noalloc: %d rays per pixel exceed the limit of %d", S.stackSize, RT_HIP_NOALLOC_MAX_SLOTS );
+	if ( S.nLights > RT_HIP_NOALLOC_MAX_LIGHTS )
+		return fail( "rt_hip_render_noalloc: %d lights exceed the limit of %d", S.nLights, RT_HIP_NOALLOC_MAX_LIGHTS );
+	HIPCHK( hipSetDevice( c->device ) );
+	unsigned char *base = g_scratch_ptr[c->device];
+	if ( !base ) return fail( "rt_hip_render_noalloc: no scratch address for device %d", c->device );
+
+	typedef NoallocLayout L;
+	Work W;
+	memset( &W, 0, sizeof( W ) );
+	const size_t per = L::cap * ( L::slots - 1 );
+	W.ctr = (Counters *) ( base + L::oCtr );
+	W.rayA = (float4 *) ( base + L::oRays );
+	W.rayB = W.rayA + per;
+	W.rayC = W.rayB + per;
+	W.rayD = W.rayC + per;
+	W.hitA = (float4 *) ( base + L::oHitA );
+	W.hitB = (uint2 *) ( base + L::oHitB );
+	W.hitN = (float4 *) ( base + L::oHitN );
+	W.res = (float4 *) ( base + L::oRes );
+	W.fac = (float4 *) ( base + L::oFac );
+	W.shadow = (float *) ( base + L::oShadow );
+	W.stackPos = (uint32_t *) ( base + L::oStackPos );
+	W.hitId = (int32_t *) ( base + L::oHitId );
+	W.spill = (uint2 *) ( base + L::oSpill );
+	W.npix = (uint32_t) npix;
+	W.cap = (uint32_t) L::cap;
+	W.tilesX = (uint32_t) ( ( S.w + 7 ) / 8 );
+	W.nChunks0 = W.tilesX * (uint32_t) ( ( S.localH + 7 ) / 8 );
+	W.spillStride = (uint32_t) RT_NOALLOC_GRID * RT_BLOCK;
+	// one stream, passes in order: one stack-overflow strip is enough
+	return enqueue_frame( c, W, (rt_argb *) d_out, 0u, false, RT_NOALLOC_GRID );
 }
 
 // after a synchronisation: did any list append of the last frame run out of room?

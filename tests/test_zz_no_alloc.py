@@ -1,0 +1,102 @@
+"""rt_hip_render_noalloc: the frame of rt_hip_render without a single
+allocation (work buffers from one fixed device array), called through the
+C-ABI and compared with rt_hip_render bit for bit: two calls in a row, the
+second on a smaller image; then its limits, and a graph capture on a context
+that has never rendered (an allocation inside a capture is an error)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes
+from raytracing_amd import types as T
+from raytracing_amd._lib import RtError, check, lib
+from raytracing_amd.pipe import RT_PARAM_STACK_SIZE, FlatTree, HipRenderer
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(w, h):
+    sc = scenes.wavy_grid_scene(48, w, h)                 # reflective + refractive grid, sphere, wall: six slots in use
+    sc.lights.append(scenes.make_light((30.0, -20.0, 10.0), 60.0, (1.0, 0.9, 0.7, 0.5)))
+    return sc
+
+
+def _noalloc(r, out):
+    L = lib()
+    L.rt_hip_render_noalloc.restype = C.c_int
+    check(L.rt_hip_render_noalloc(r._c, C.c_void_p(out.data_ptr()), C.c_uint(0)), "rt_hip_render_noalloc")
+
+
+def test_noalloc_frames_equal_the_allocating_entry_point():
+    import torch
+    sc = _scene(200, 144)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 18, 5)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        r = HipRenderer(0, stream=s.cuda_stream)
+        r.load_scene(sc, tree)
+        for w, h in [(200, 144), (96, 64)]:              # the second call on a smaller image
+            r.set_camera(scenes.make_camera(w, h))
+            r.set_image(w, h)
+            a = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            b = torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda")
+            r.render(0, d_out=a.data_ptr())
+            _noalloc(r, b)
+            r.sync()
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert a.any() and np.array_equal(a, b), (w, h)
+        # limits are errors, not clipped frames
+        out = torch.zeros((512 * 512 * 4,), dtype=torch.uint8, device="cuda")
+        r.set_image(512, 512)
+        with pytest.raises(RtError, match="exceed the limit"):
+            _noalloc(r, out)
+        r.set_image(96, 64)
+        r.upload_lights(np.array([scenes.make_light((0.0, -50.0, 0.0), 50.0)] * 5, T.point_light))
+        with pytest.raises(RtError, match="lights exceed"):
+            _noalloc(r, out)
+        r.upload_lights(sc.light_table())
+        r.set_param(RT_PARAM_STACK_SIZE, 8)
+        with pytest.raises(RtError, match="rays per pixel"):
+            _noalloc(r, out)
+        r.set_param(RT_PARAM_STACK_SIZE, sc.stack_size)
+        L = lib()
+        assert L.rt_hip_render_noalloc(r._c, C.c_void_p(out.data_ptr()), C.c_uint(1)) != 0      # flags
+        assert L.rt_hip_render_noalloc(r._c, None, C.c_uint(0)) != 0                             # no output buffer
+        _noalloc(r, out)                                                                        # and it still works
+        r.sync()
+        r.close()
+    tree.release()
+
+
+def test_noalloc_frame_in_a_graph_on_a_context_that_never_rendered():
+    import torch
+    sc = _scene(160, 96)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 14, 7)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ref = HipRenderer(0, stream=s.cuda_stream)
+        ref.load_scene(sc, tree)
+        want = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda")
+        ref.render(0, d_out=want.data_ptr())
+        ref.sync()
+        want = want.cpu().numpy()
+        ref.close()
+
+        r = HipRenderer(0, stream=s.cuda_stream)          # never calls rt_hip_render: owns no work buffers
+        r.load_scene(sc, tree)
+        out = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda")
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            _noalloc(r, out)
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            s.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+        del g
+        r.close()
+    tree.release()
