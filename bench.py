@@ -3,10 +3,16 @@
 
 One step = one frame of the workload: ray generation, kd-tree closest-hit
 passes, shadow + shading passes and the colour fold, with the scene, the tree
-and all work buffers already resident in HBM.  With --gpus N the same frame is
-split into bands of 16 rows dealt round-robin to the N ranks (scene
-replicated) and the finished rows are gathered on rank 0 with one RCCL
-collective, inside the timed region ("strong" scaling: the frame is fixed).
+and all work buffers already resident in HBM.
+
+  config3 (default) / config2   one fixed frame.  With --gpus N the frame is
+      split into bands of 16 rows dealt round-robin to the N ranks (scene
+      replicated) and the finished rows are gathered on rank 0 through the
+      library's C-ABI (RCCL send / receive + de-interleave kernel), inside
+      the timed region: "strong" scaling, the frame is fixed.
+  config5                       the fly-through: step i of rank r renders
+      camera (i * N + r) mod 240 of the orbit, whole frames, no exchange:
+      "weak" scaling, every rank renders K frames.
 
 Prints ONE JSON line on rank 0.  `value` is whole-job Mrays/s, a ray being
 one closest-hit query or one shadow query (counted by the kernels' own work
@@ -37,18 +43,26 @@ from raytracing_amd import dist as rdist
 from raytracing_amd import scenes
 from raytracing_amd.pipe import RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_OVERLAP, DeviceTree, FlatTree, HipRenderer
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
+# roofs: HBM3E spec; L2 and Infinity Cache as measured chip-wide for gathered rows (the access
+# shape of this path), the upper end of the ranges
+HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 18800.0
+MALL_PEAK_GBS = 8600.0
 
 # kd-tree of the benchmark: the reference's split rule with its two limits made
 # run-time parameters (the reference's fixed depth 10 leaves ~2000 triangles
 # per leaf on this scene)
 TREE_DEPTH, TREE_LEAF = 26, 12
+ORBIT_FRAMES = 240
 
 WORKLOADS = {
     "config3": dict(make=scenes.config3, text="1M-triangle displaced sphere + floor, 3840x2160, "
                     "opaque reflective material, 5 rays per pixel (primary + 4 bounces), 1 point light"),
     "config2": dict(make=scenes.config2, text="100k-triangle displaced sphere + floor, 1920x1080, "
                     "primary + shadow rays, 1 point light"),
+    "config5": dict(make=scenes.config5, text="fly-through: 1M-triangle displaced sphere + floor, 3840x2160, reflective + "
+                    "refractive material (incoherent secondary rays), 6 rays per pixel, 1 point light, "
+                    f"camera on a {ORBIT_FRAMES}-frame orbit, frame f on rank f mod N"),
 }
 
 
@@ -58,38 +72,53 @@ def algorithmic_bytes(nodes, tris, primary, hits):
     return 8 * nodes + 48 * tris + 4 * primary + 128 * hits
 
 
-def measured_traffic(args, kernel, world):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter
-    passes of this same command (profiles/r01_traffic.json: FETCH_SIZE doubled
-    as the gfx950 correction prescribes, plus WRITE_SIZE), or None when that
-    file does not cover this configuration.  Counters cannot be read live."""
+def committed_counters(args, kernel, world):
+    """What the committed rocprofv3 counter passes of this same frame say about
+    `kernel` (profiles/r02_counters.json, written by tools/refresh_profiles.py:
+    fabric traffic per launch with the gfx950 FETCH_SIZE correction, and the
+    ratios that show what binds the kernel), or None when that file does not
+    cover this configuration.  Counters cannot be read live."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
     except (OSError, ValueError):
         return None
     key = f"{args.workload}/depth{args.depth}/leaf{args.leaf}/gpus{world}/{'serial' if args.no_overlap else 'overlap'}"
     return t.get(key, {}).get("k_" + kernel)
 
 
-def cpu_baseline(sc, tree, seconds=15.0):
-    """The CPU restatement (oracle, checker-only code) timed on a bounded
-    lattice of the same frame and the same tree."""
+def cpu_baseline(sc, v, t, tree, seconds):
+    """The CPU restatement (oracle, checker-only code) timed on bounded lattices
+    of the same frame: on the benchmark's tree, and on the tree the reference's
+    own limits give (depth 10, leaves of at most 7 - rt_types.h:16-17), which on
+    this scene leaves ~2000 triangles per leaf."""
     from oracle import orc
-    nodes, idx = tree.expand()
     threads = min(os.cpu_count() or 1, 16)
-    step, rays, dt = 64, 0, 1e-3
-    for _ in range(4):
-        t0 = time.time()
-        _, _, st = orc.raytrace(sc, tree.bbox, nodes, idx, x_step=step, y_step=step, threads=threads, want_hits=False)
-        dt = max(time.time() - t0, 1e-3)
-        rays = st["raysClosest"] + st["raysShadow"]
-        if dt >= 0.5 * seconds or step == 1:
-            break
-        # denser lattice so that the run takes about `seconds`
-        step = int(max(1, min(step - 1, step * (dt / seconds) ** 0.5)))
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": ("the whole frame" if step == 1 else f"every {step}th pixel of every {step}th row of the same frame")
-                      + f" on the same tree ({rays} rays in {dt:.1f} s on {threads} threads)"}
+
+    def timed(nodes, idx, bbox, budget, step0):
+        step, rays, dt = step0, 0, 1e-3
+        for _ in range(4):
+            t0 = time.time()
+            _, _, st = orc.raytrace(sc, bbox, nodes, idx, x_step=step, y_step=step, threads=threads, want_hits=False)
+            dt = max(time.time() - t0, 1e-3)
+            rays = st["raysClosest"] + st["raysShadow"]
+            if dt >= 0.5 * budget or step == 1:
+                break
+            step = int(max(1, min(step - 1, step * (dt / budget) ** 0.5)))     # denser lattice, about `budget` seconds
+        what = "the whole frame" if step == 1 else f"every {step}th pixel of every {step}th row of the same frame"
+        return rays / dt / 1e6, f"{what} ({rays} rays in {dt:.1f} s on {threads} threads)"
+
+    nodes, idx = tree.expand()
+    deep, deep_txt = timed(nodes, idx, tree.bbox, 0.6 * seconds, 64)
+    ref_tree = FlatTree.build(v, t, 10, 7)
+    rn, ri = ref_tree.expand()
+    shallow, shallow_txt = timed(rn, ri, ref_tree.bbox, 0.4 * seconds, 256)
+    ref_tree.release()
+    return {"value": round(deep, 4), "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": deep_txt + " on the benchmark's tree",
+            "reference_limits": {"value": round(shallow, 5), "unit": "Mrays/s", "cores": threads,
+                                 "tree": "depth 10, at most 7 triangles per leaf unless the depth limit is hit (the reference's "
+                                         "MAX_DEPTH / MAX_PRIMS_IN_NODE): what the reference's algorithm costs on this scene",
+                                 "sample": shallow_txt}}
 
 
 def main():
@@ -101,9 +130,10 @@ def main():
     ap.add_argument("--depth", type=int, default=TREE_DEPTH)
     ap.add_argument("--leaf", type=int, default=TREE_LEAF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy (1-GPU runs of a frame workload)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -121,6 +151,7 @@ def main():
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl") needs one GPU per rank; RT_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU
@@ -130,6 +161,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    sequence = args.workload == "config5"
     wl = WORKLOADS[args.workload]
     sc = wl["make"]()
     v, t = sc.flatten()
@@ -149,56 +181,107 @@ def main():
     r = HipRenderer(local_dev, stream=stream.cuda_stream)
     r.load_scene(sc, tree)
     r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
-    r.set_tile(rdist.BAND_H, world, rank)
+    split = world > 1 and not sequence
+    if split:
+        r.set_tile(rdist.BAND_H, world, rank)
     rows = r.local_rows
-    pad = rdist.padded_rows(sc.h, rdist.BAND_H, world)
+    pad = rdist.padded_rows(sc.h, rdist.BAND_H, world) if split else sc.h
     frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
 
-    dbg = bool(os.environ.get("RT_BENCH_TRACE"))     # debugging aid: synchronise and report after every frame
+    # ---- frame exchange of the split frame: the library's own RCCL gather; torch.distributed's gather (also RCCL)
+    # only where that cannot run (gloo rehearsals on one GPU) or fails to start, and the JSON line says which
+    comm, frame_full, gather_kind = None, None, None
+    if split:
+        if backend == "nccl":
+            try:
+                idt = torch.zeros(rdist.HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(rdist.HipComm.unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                comm = rdist.HipComm(local_dev, world, rank, bytes(idt.cpu().numpy().tobytes()))
+                frame_full = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+                gather_kind = "rt_hip_gather_frame (C-ABI: RCCL send/receive to rank 0 + de-interleave kernel)"
+            except Exception as e:                                     # noqa: BLE001 - reported in the JSON line
+                comm = None
+                gather_kind = f"torch.distributed.gather over RCCL (rt_hip_comm_create failed: {e})"
+            ok = torch.tensor([1 if comm else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()) and comm:
+                comm.close()
+                comm = None
+                gather_kind = "torch.distributed.gather over RCCL (a rank could not create the C-ABI communicator)"
+        else:
+            gather_kind = f"torch.distributed.gather over {backend} (rehearsal: ranks share a GPU, which RCCL refuses)"
 
-    def step(flags=0):
+    trace = bool(os.environ.get("RT_BENCH_TRACE"))     # debugging aid: synchronise and report after every frame
+
+    def camera_of(step_index):
+        return scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world((step_index * world + rank) % ORBIT_FRAMES, ORBIT_FRAMES))
+
+    def step(i, flags=0):
+        if sequence:
+            r.set_camera(camera_of(i))
         r.render(flags, d_out=frame_local.data_ptr())
-        if dbg:
+        if trace:
             r.sync()
             print(f"[rank {rank}] frame rendered", file=sys.stderr, flush=True)
-        if world > 1:
-            out = rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
-            if dbg:
-                print(f"[rank {rank}] frame gathered", file=sys.stderr, flush=True)
-            return out
-        return frame_local
+        if not split:
+            return frame_local
+        if comm:
+            comm.gather(frame_local, frame_full, sc.h, sc.w, rdist.BAND_H, 0, stream.cuda_stream)
+            return frame_full
+        return rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    if split and comm and args.warmup:
+        # the two gathers must agree (both outside the timed region)
+        fence()
+        want = rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
+        if rank == 0 and not torch.equal(want, frame_full):
+            raise SystemExit("rt_hip_gather_frame and torch.distributed.gather assembled different frames")
     fence()
 
     # ---- timed region: exactly K steps ------------------------------------
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(RT_HIP_TIMING)
+    for i in range(args.steps):
+        step(args.warmup + i, RT_HIP_TIMING)
     fence()
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times, averaged over the timed steps (the events are
     # recorded on the stream the kernels run on); read after the timed region
-    kms, launches = r.kernel_times()
-    st = r.stats()                      # ray counters of the last frame (identical for every frame)
+    kms, launches, wall = r.kernel_times_wall()
+
+    # rays of the timed steps (work-list counters; for a sequence every camera is rendered again, untimed)
+    if sequence:
+        rc = rs = hits = 0
+        for i in range(args.steps):
+            r.set_camera(camera_of(args.warmup + i))
+            r.render(0, d_out=frame_local.data_ptr())
+            st = r.stats()
+            rc, rs, hits = rc + st["raysClosest"], rs + st["raysShadow"], hits + st["hits"]
+        cnt = torch.tensor([rc, rs, hits], dtype=torch.float64, device=dev)
+    else:
+        st = r.stats()                  # ray counters of the last frame (identical for every frame)
+        cnt = torch.tensor([st["raysClosest"], st["raysShadow"], st["hits"]], dtype=torch.float64, device=dev) * args.steps
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([st["raysClosest"], st["raysShadow"], st["hits"]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
-    rays_frame = float(cnt[0] + cnt[1])
+    rays_total = float(cnt[0] + cnt[1])
 
     # ---- outside the timed region: the same frame with every pass alone on the
     # chip (what a kernel takes when it does not share the GPU with the passes
     # that the normal schedule runs beside it)
+    if sequence:
+        r.set_camera(camera_of(args.warmup))
     r.set_param(RT_PARAM_OVERLAP, 0)
     for _ in range(3):
         r.render(RT_HIP_TIMING, d_out=frame_local.data_ptr())
@@ -222,51 +305,94 @@ def main():
         "shade": 128 * sst["hits"],
         "fold": 4 * primary,
     }
-    dominant = max(("closest", "shadow", "shade"), key=lambda k: kms[k])
-    dom_bytes, dom_ms = kbytes[dominant], kms[dominant]
+    dominant = max(("closest", "shadow", "shade"), key=lambda k: wall[k])
+    dom_bytes = kbytes[dominant]
     n_launch = max(launches.get(dominant, 1), 1)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    achieved = gbs(dom_bytes, wall[dominant])
     frame_bytes = algorithmic_bytes(sst["nodeVisits"], sst["triTests"], primary, sst["hits"])
+    all_rays = max(sst["raysClosest"] + sst["raysShadow"], 1)
 
-    out = None
+    # ---- strong-scaling proxy: what one rank of an N-GPU split of this frame takes on this GPU
+    proxy = None
+    if world == 1 and not sequence and not args.no_proxy:
+        proxy = {}
+        for parts in (2, 4, 8):
+            r.set_tile(rdist.BAND_H, parts, 0)
+            part_out = torch.zeros((rdist.padded_rows(sc.h, rdist.BAND_H, parts), sc.w, 4), dtype=torch.uint8, device=dev)
+            for _ in range(2):
+                r.render(0, d_out=part_out.data_ptr())
+            r.sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                r.render(0, d_out=part_out.data_ptr())
+            r.sync()
+            proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+        r.set_tile(rdist.BAND_H, 1, 0)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = rays_frame * args.steps / elapsed / 1e6
+        value = rays_total / elapsed / 1e6
+        if proxy is not None:
+            proxy["full_frame_ms"] = round(ms_per_step, 4)
+            proxy["note"] = ("time of rank 0's share of an N-way band split of this frame on ONE GPU, render only (no exchange): "
+                             "full_frame_ms / part_0_of_N_ms bounds the N-GPU speed-up from above")
+        counters = committed_counters(args, dominant, world)
         out = {
-            "metric": "Mrays/s (primary+shadow) on 1M-tri scene at 4K" if args.workload == "config3"
+            "metric": "Mrays/s (primary+shadow) on 1M-tri scene at 4K" if args.workload in ("config3", "config5")
                       else "Mrays/s (primary+shadow)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if sequence else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['text']}",
                        "kd_tree": {"max_depth": args.depth, "max_prims_in_leaf": args.leaf, "depth": int(tree.depth),
                                    "nodes": int(len(tree.nodes)), "triangle_refs": int(len(tree.recs)),
                                    "host_build_s": round(build_s, 3), "gpu_build_s": round(gpu_build_s, 4)},
                        "schedule": "passes in order on one stream" if args.no_overlap else
                                    "closest-hit chain on the main stream, shadow + lighting passes on two auxiliary "
-                                   "streams (they overlap the chain; per-kernel times include the time a pass shares the chip)",
-                       "rays_per_frame": int(rays_frame), "closest_rays": int(cnt[0]), "shadow_rays": int(cnt[1]),
+                                   "streams (they overlap the chain)",
+                       "rays_per_step": int(rays_total / args.steps), "closest_rays_per_step": int(cnt[0] / args.steps),
+                       "shadow_rays_per_step": int(cnt[1] / args.steps),
+                       "frames_per_s": round(args.steps * (world if sequence else 1) / elapsed, 3),
                        "parallelism": "single GPU" if world == 1 else
-                                      f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "
-                                      "rows gathered on rank 0 (RCCL)"},
+                                      (f"frame f of the sequence on rank f mod {world}, scene replicated, no exchange" if sequence else
+                                       f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "
+                                       f"rows gathered on rank 0: {gather_kind}")},
+            # sums of launch durations (launches that run side by side add up: can exceed the frame time)
             "kernel_ms_per_frame_rank0": {k: round(x, 4) for k, x in kms.items()},
+            # wall-clock time during which at least one launch of the kernel ran (never exceeds the frame time)
+            "kernel_wall_ms_per_frame_rank0": {k: round(x, 4) for k, x in wall.items()},
             "kernel_ms_per_frame_isolated_rank0": {k: round(x, 4) for k, x in kms_iso.items()},
             "roofline": {"bound": "hbm", "kernel": "k_" + dominant,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args, dominant, world),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": counters.get("fabric_bytes_per_launch") if counters else None,
+                         "time_basis": "wall-attributed: algorithmic bytes of the kernel's launches of one frame / the time during "
+                                       "which at least one of them ran (HIP events on the streams they run on, timed region)",
                          "launches_per_frame": n_launch,
                          "algorithmic_bytes_per_launch": int(dom_bytes / n_launch),
-                         "avg_launch_ms": round(dom_ms / n_launch, 4),
+                         "avg_launch_ms": round(kms[dominant] / n_launch, 4),
+                         "avg_launch_ms_isolated": round(kms_iso[dominant] / n_launch, 4),
+                         "achieved_isolated": round(gbs(dom_bytes, kms_iso[dominant]), 2),
+                         # the working set (0.26 GB) is served by L2 and the Infinity Cache, so these are the roofs that can bind
+                         "frac_of_l2_roof": round(achieved / L2_PEAK_GBS, 5), "l2_peak": L2_PEAK_GBS,
+                         "frac_of_infinity_cache_roof": round(achieved / MALL_PEAK_GBS, 5), "infinity_cache_peak": MALL_PEAK_GBS,
                          "frame_algorithmic_bytes": int(frame_bytes),
-                         "frame_achieved_GBs": round(frame_bytes / (kms["frame"] * 1e-3) / 1e9, 2),
-                         "per_ray": {"nodes": round(sst["nodeVisits"] / max(sst["raysClosest"] + sst["raysShadow"], 1), 2),
-                                     "tri_tests": round(sst["triTests"] / max(sst["raysClosest"] + sst["raysShadow"], 1), 2)}},
+                         "frame_achieved_GBs": round(gbs(frame_bytes, kms["frame"]), 2),
+                         "per_ray": {"nodes": round(sst["nodeVisits"] / all_rays, 2), "tri_tests": round(sst["triTests"] / all_rays, 2)},
+                         "traversal_stack": {"deepest": int(sst["maxStack"]), "pushes_beyond_lds": int(sst["spillPushes"]),
+                                             "rays": int(all_rays)},
+                         "counters": counters},
         }
+        if proxy is not None:
+            out["strong_scaling_proxy"] = proxy
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, tree, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(sc, v, t, tree, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if comm:
+        comm.close()
     r.close()
     if world > 1:
         dist.barrier()

@@ -188,12 +188,38 @@ int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
  * With RT_PARAM_OVERLAP = 1 passes share the chip, so ms[0..3] add up to more
  * than ms[4]; set it to 0 to time every pass running alone. */
 int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );
+/* The same plus wall[0..3]: per kernel (closest, shadow, lighting, fold) the wall-clock time per frame during which at
+ * least one of its launches was running (length of the union of its launch intervals).  Unlike ms[], which adds up
+ * launches that run side by side, wall[] never exceeds the frame time. */
+int  rt_hip_kernel_times_ex( rt_hip_ctx *c, float ms[5], int launches[5], float wall[4] );
 /* Device self-test (no reference counterpart): the triangle test replaces the
  * IEEE division 1 / det by a hardware reciprocal plus one Newton step where
  * that is exact.  Evaluates both for all 2^32 float bit patterns; *mismatches
  * = inputs for which the value the kernels would use differs from the
  * division (must be 0), *fastPath = inputs that take the short path. */
 int  rt_hip_selftest_rcp( rt_hip_ctx *c, uint64_t *mismatches, uint64_t *fastPath );
+
+/* ---- multi-GPU frame assembly (no reference counterpart: the reference renders on one device) ------------------
+ *
+ * One process per GPU, the scene replicated, the image cut into bands of bandH rows dealt round-robin to the ranks
+ * (rt_hip_set_tile).  rt_hip_gather_frame moves every rank's compact share to rank `dst` over RCCL (send / receive in
+ * one group: every source uses its own xGMI link) and de-interleaves the shares into the frame there.  d_local must
+ * hold rt_hip_gather_rows(h, bandH, nRanks) rows (the largest share, whole bands; the rows beyond this rank's own share
+ * are never shown), d_frame (destination rank only) h rows, both of w rt_argb, in device memory.  Asynchronous on
+ * `hipStream`; collective: every rank of the communicator must call it.  Errors: rt_hip_comm_last_error().
+ * RCCL is opened with dlopen at the first rt_hip_comm_* call.                                                        */
+typedef struct rt_hip_comm rt_hip_comm;
+#define RT_HIP_COMM_ID_BYTES 128
+const char *rt_hip_comm_last_error( void );
+/* rank 0 makes an id and hands its bytes to the other ranks by whatever means the application has (file, socket, MPI) */
+int  rt_hip_comm_unique_id( void *id128 );
+rt_hip_comm *rt_hip_comm_create( int device, int nRanks, int rank, const void *id128 );     /* NULL on failure; collective */
+void rt_hip_comm_destroy( rt_hip_comm *comm );
+int  rt_hip_gather_rows( int h, int bandH, int nParts );
+int  rt_hip_gather_frame( rt_hip_comm *comm, const void *d_local, void *d_frame, int w, int h, int bandH, int dst, void *hipStream );
+/* the second half alone, for callers with their own transport: d_stage holds nParts shares of
+ * rt_hip_gather_rows() rows each, share r first band = band r of the image */
+int  rt_hip_deinterleave( const void *d_stage, void *d_frame, int w, int h, int bandH, int nParts, void *hipStream );
 
 #ifdef __cplusplus
 }

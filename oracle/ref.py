@@ -18,7 +18,9 @@ SO = os.path.join(HERE, "_ref", "librt_ref.so")
 
 
 def available():
-    return os.path.exists(SO)
+    # RT_NO_LIVE_REFERENCE: sanitizer runs of the product's host code (tools/run_asan.sh) leave the
+    # reference's own library out - its allocations are not the sanitizer's business
+    return os.path.exists(SO) and not os.environ.get("RT_NO_LIVE_REFERENCE")
 
 
 class CountInfo(C.Structure):

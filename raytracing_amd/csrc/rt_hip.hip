@@ -2928,29 +2928,65 @@ int rt_hip_selftest_rcp( rt_hip_ctx *c, uint64_t *mismatches, uint64_t *fastPath
 
 int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 {
+	return rt_hip_kernel_times_ex( c, ms, launches, nullptr );
+}
+
+int rt_hip_kernel_times_ex( rt_hip_ctx *c, float ms[5], int launches[5], float wall[4] )
+{
 	if ( !c || !ms || !launches ) return fail( "rt_hip_kernel_times: bad arguments" );
 	if ( c->timedFrames == 0 ) return fail( "rt_hip_kernel_times: no frame was rendered with RT_HIP_TIMING since the last call" );
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	for ( int i = 0; i < 5; ++i ) ms[i] = 0.0f;
+	if ( wall ) for ( int i = 0; i < 4; ++i ) wall[i] = 0.0f;
 	const int n = c->timedSlots;
 	const int frames = c->timedFrames < RT_TIMED_FRAMES ? c->timedFrames : RT_TIMED_FRAMES;
 	for ( int f = 0; f < frames; ++f )
 	{
 		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
+		hipEvent_t frame0 = ev[6 * RT_MAX_SLOTS + 2];
 		float t = 0.0f;
-		for ( int k = 0; k < n; ++k )
-			for ( int j = 0; j < 3; ++j )             // closest, shadow, light
+		for ( int j = 0; j < 3; ++j )             // closest, shadow, light
+		{
+			// launch intervals of this kernel relative to the start of the frame
+			float a[RT_MAX_SLOTS], b[RT_MAX_SLOTS];
+			for ( int k = 0; k < n; ++k )
 			{
 				HIPCHK( hipEventElapsedTime( &t, ev[6 * k + 2 * j], ev[6 * k + 2 * j + 1] ) );
 				ms[j] += t;
+				if ( wall )
+				{
+					HIPCHK( hipEventElapsedTime( &a[k], frame0, ev[6 * k + 2 * j] ) );
+					b[k] = a[k] + t;
+				}
 			}
+			if ( wall )
+			{
+				// length of the union of the intervals: the wall-clock time during which
+				// at least one launch of this kernel was running
+				for ( int x = 1; x < n; ++x )
+					for ( int y = x; y > 0 && a[y] < a[y - 1]; --y )
+					{
+						float ta = a[y], tb = b[y];
+						a[y] = a[y - 1]; b[y] = b[y - 1];
+						a[y - 1] = ta; b[y - 1] = tb;
+					}
+				float end = -1.0f;
+				for ( int k = 0; k < n; ++k )
+				{
+					const float lo = a[k] > end ? a[k] : end;
+					if ( b[k] > lo ) { wall[j] += b[k] - lo; end = b[k]; }
+				}
+			}
+		}
 		HIPCHK( hipEventElapsedTime( &t, ev[6 * RT_MAX_SLOTS], ev[6 * RT_MAX_SLOTS + 1] ) );
 		ms[3] += t;
+		if ( wall ) wall[3] += t;
 		HIPCHK( hipEventElapsedTime( &t, ev[6 * RT_MAX_SLOTS + 2], ev[6 * RT_MAX_SLOTS + 3] ) );
 		ms[4] += t;
 	}
 	for ( int i = 0; i < 5; ++i ) ms[i] /= (float) frames;
+	if ( wall ) for ( int i = 0; i < 4; ++i ) wall[i] /= (float) frames;
 	launches[0] = launches[1] = launches[2] = n;
 	launches[3] = 1;
 	launches[4] = 3 * n + 1;

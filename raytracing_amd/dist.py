@@ -101,3 +101,68 @@ def sequence_frames(n_frames, n_parts, part, start=0):
     changes), so a sequence needs no collective at all."""
     first = start + ((part - start) % n_parts)
     return list(range(first, n_frames, n_parts))
+
+
+# ---------------------------------------------------------------------------
+# the same exchange through the library's own C-ABI (RCCL send / receive +
+# de-interleave kernel, raytracing_amd/csrc/gather.hip): what a C caller of the
+# render-pipe API uses, and what bench.py times on GPUs
+# ---------------------------------------------------------------------------
+
+class HipComm:
+    """One rt_hip_comm: this rank's end of an RCCL communicator over `n_ranks` GPUs."""
+
+    ID_BYTES = 128
+
+    def __init__(self, device, n_ranks, rank, unique_id):
+        import ctypes as C
+        from ._lib import RtError, lib
+        self._L = lib()
+        self._L.rt_hip_comm_create.restype = C.c_void_p
+        self._L.rt_hip_comm_last_error.restype = C.c_char_p
+        self.n_ranks, self.rank = n_ranks, rank
+        buf = (C.c_char * self.ID_BYTES).from_buffer_copy(bytes(unique_id))
+        h = self._L.rt_hip_comm_create(C.c_int(device), C.c_int(n_ranks), C.c_int(rank), buf)
+        if not h:
+            raise RtError("rt_hip_comm_create: " + self._L.rt_hip_comm_last_error().decode())
+        self._h = C.c_void_p(h)
+
+    @staticmethod
+    def unique_id():
+        """bytes of a fresh communicator id (call on one rank, hand to the others)"""
+        import ctypes as C
+        from ._lib import RtError, lib
+        L = lib()
+        L.rt_hip_comm_last_error.restype = C.c_char_p
+        buf = (C.c_char * HipComm.ID_BYTES)()
+        if L.rt_hip_comm_unique_id(buf):
+            raise RtError("rt_hip_comm_unique_id: " + L.rt_hip_comm_last_error().decode())
+        return bytes(buf)
+
+    def gather(self, local, frame, h, w, band_h=BAND_H, dst=0, stream=None):
+        """local: device tensor of at least padded_rows() rows; frame: [h, w, 4] device tensor on rank dst (else None)."""
+        import ctypes as C
+        from ._lib import RtError
+        assert local.shape[0] >= padded_rows(h, band_h, self.n_ranks) and local.is_contiguous()
+        rc = self._L.rt_hip_gather_frame(self._h, C.c_void_p(local.data_ptr()),
+                                         C.c_void_p(frame.data_ptr()) if frame is not None else None,
+                                         C.c_int(w), C.c_int(h), C.c_int(band_h), C.c_int(dst), C.c_void_p(stream))
+        if rc:
+            raise RtError("rt_hip_gather_frame: " + self._L.rt_hip_comm_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.rt_hip_comm_destroy(self._h)
+            self._h = None
+
+
+def deinterleave(stage, frame, band_h, n_parts, stream=None):
+    """rt_hip_deinterleave: stage [n_parts, padded_rows, w, 4] -> frame [h, w, 4], both device tensors."""
+    import ctypes as C
+    from ._lib import RtError, lib
+    h, w = frame.shape[0], frame.shape[1]
+    L = lib()
+    L.rt_hip_comm_last_error.restype = C.c_char_p
+    if L.rt_hip_deinterleave(C.c_void_p(stage.data_ptr()), C.c_void_p(frame.data_ptr()), C.c_int(w), C.c_int(h),
+                             C.c_int(band_h), C.c_int(n_parts), C.c_void_p(stream)):
+        raise RtError("rt_hip_deinterleave: " + L.rt_hip_comm_last_error().decode())

@@ -281,6 +281,16 @@ class HipRenderer:
         names = ("closest", "shadow", "shade", "fold", "frame")
         return dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n]))
 
+    def kernel_times_wall(self):
+        """kernel_times() plus, per kernel, the wall-clock ms per frame during which at least one of its launches ran."""
+        ms = (C.c_float * 5)()
+        n = (C.c_int * 5)()
+        wall = (C.c_float * 4)()
+        check(self._L.rt_hip_kernel_times_ex(self._c, ms, n, wall), "rt_hip_kernel_times_ex")
+        names = ("closest", "shadow", "shade", "fold", "frame")
+        return (dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n])),
+                dict(zip(names[:4], [float(x) for x in wall])))
+
     def selftest_rcp(self):
         """(mismatches, fast-path inputs) of the exact-reciprocal shortcut over all 2^32 floats."""
         bad, fast = C.c_uint64(0), C.c_uint64(0)

@@ -80,3 +80,39 @@ def test_sequence_frames_partition(n, parts):
     got = [rdist.sequence_frames(n, parts, p) for p in range(parts)]
     assert sorted(f for g in got for f in g) == list(range(n))
     assert all(f % parts == p for p, g in enumerate(got) for f in g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,band,parts", [(64, 40, 16, 2), (70, 33, 16, 3), (135, 17, 8, 8), (50, 64, 5, 4), (16, 8, 16, 1)])
+def test_device_deinterleave_is_the_band_mapping(h, w, band, parts):
+    """rt_hip_deinterleave (the second half of rt_hip_gather_frame) puts local band b of share r at band b * N + r."""
+    import torch
+    from raytracing_amd import dist as rdist
+    pad = rdist.padded_rows(h, band, parts)
+    rng = np.random.RandomState(h * w + parts)
+    full = rng.randint(0, 256, (h, w, 4)).astype(np.uint8)
+    stage = rng.randint(0, 256, (parts, pad, w, 4)).astype(np.uint8)      # rows beyond a share: never shown
+    for p in range(parts):
+        rows = rdist.band_rows(h, band, parts, p)
+        stage[p, :len(rows)] = full[rows]
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    rdist.deinterleave(torch.from_numpy(stage).cuda(), out, band, parts)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), full)
+
+
+@pytest.mark.gpu
+def test_rccl_gather_through_the_c_abi_single_rank():
+    """The whole C-ABI path with a one-rank communicator (the box has one GPU; RCCL refuses two ranks on one device):
+    unique id, communicator, gather = own share through the staging buffer and the de-interleave kernel."""
+    import torch
+    from raytracing_amd import dist as rdist
+    h, w = 72, 48
+    comm = rdist.HipComm(0, 1, 0, rdist.HipComm.unique_id())
+    local = torch.randint(0, 256, (rdist.padded_rows(h, 16, 1), w, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        comm.gather(local, frame, h, w, 16, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(frame, local[:h])
+    comm.close()

@@ -36,7 +36,7 @@ def test_two_ranks_on_one_gpu_trace_the_same_frame():
     one = run_bench(1, 0)
     two = run_bench(2, 29533)
     assert (one["n_gpus"], two["n_gpus"]) == (1, 2) and two["scaling"] == "strong"
-    for k in ("rays_per_frame", "closest_rays", "shadow_rays"):
+    for k in ("rays_per_step", "closest_rays_per_step", "shadow_rays_per_step"):
         assert one["config"][k] == two["config"][k], k
     assert two["cpu_baseline"] is None and two["roofline"]["traffic"] is None
     assert "bands of 16 rows over 2 GPUs" in two["config"]["parallelism"]
