@@ -28,12 +28,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# A frame runs on three streams of its own (closest-hit chain + two auxiliary ones); with the
-# collective library's streams on top a rank would exceed the runtime's default of four
-# hardware queues per process and two of them would be folded into one queue, which
-# serialises what is meant to overlap.  Must be set before the HIP runtime starts.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# A frame runs on three streams (closest-hit chain + two auxiliary ones) and two frames are in
+# flight; with the null stream (the kd-tree builder's) and the collective library's streams a rank
+# uses nine to twelve.  The runtime's default of four hardware queues per process folds several
+# streams into one queue, which serialises what is meant to overlap: measured, a frame of two in
+# flight costs 7.2 ms at 8 queues (one stream too few) and 6.8 ms from 10 on.  Must be set before
+# the HIP runtime starts (the machine exports 4, hence an assignment).
+os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 import numpy as np
 import torch
@@ -134,6 +135,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
+                         "buffers, one shared scene), so a frame's sparse last passes overlap the next frame's first ones")
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -177,41 +181,64 @@ def main():
     assert (dtree.n_nodes, dtree.n_recs) == (len(tree.nodes), len(tree.recs))
     dtree.release()
 
-    stream = torch.cuda.current_stream()
-    r = HipRenderer(local_dev, stream=stream.cuda_stream)
-    r.load_scene(sc, tree)
-    r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
     split = world > 1 and not sequence
-    if split:
-        r.set_tile(rdist.BAND_H, world, rank)
-    rows = r.local_rows
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world) if split else sc.h
-    frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
+    n_slots = max(1, min(args.in_flight, 4))
 
-    # ---- frame exchange of the split frame: the library's own RCCL gather; torch.distributed's gather (also RCCL)
-    # only where that cannot run (gloo rehearsals on one GPU) or fails to start, and the JSON line says which
-    comm, frame_full, gather_kind = None, None, None
+    # ---- one context per frame in flight: own stream, own work buffers, own output and exchange; the scene is
+    # resident once and shared
+    class Slot:
+        pass
+
+    slots = []
+    for k in range(n_slots):
+        sl = Slot()
+        sl.stream = torch.cuda.Stream()          # (not the default stream: work on it would wait for, and hold up, the other frame)
+        sl.r = HipRenderer(local_dev, stream=sl.stream.cuda_stream)
+        if k == 0:
+            sl.r.load_scene(sc, tree)
+        else:
+            sl.r.share_scene(slots[0].r, sc)
+        sl.r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
+        if split:
+            sl.r.set_tile(rdist.BAND_H, world, rank)
+        sl.frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
+        sl.comm, sl.frame_full = None, None
+        slots.append(sl)
+    torch.cuda.synchronize()                     # buffers were zeroed on torch's default stream
+    r = slots[0].r
+    rows = r.local_rows
+    frame_local = slots[0].frame_local
+
+    # ---- frame exchange of the split frame: the library's own RCCL gather (one communicator per frame in flight);
+    # torch.distributed's gather (also RCCL) only where that cannot run (gloo rehearsals on one GPU) or fails to
+    # start, and the JSON line says which
+    gather_kind = None
     if split:
         if backend == "nccl":
             try:
-                idt = torch.zeros(rdist.HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(rdist.HipComm.unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, 0)
-                comm = rdist.HipComm(local_dev, world, rank, bytes(idt.cpu().numpy().tobytes()))
-                frame_full = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+                for sl in slots:
+                    idt = torch.zeros(rdist.HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        idt.copy_(torch.frombuffer(bytearray(rdist.HipComm.unique_id()), dtype=torch.uint8))
+                    dist.broadcast(idt, 0)
+                    sl.comm = rdist.HipComm(local_dev, world, rank, bytes(idt.cpu().numpy().tobytes()))
+                    sl.frame_full = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
                 gather_kind = "rt_hip_gather_frame (C-ABI: RCCL send/receive to rank 0 + de-interleave kernel)"
             except Exception as e:                                     # noqa: BLE001 - reported in the JSON line
-                comm = None
                 gather_kind = f"torch.distributed.gather over RCCL (rt_hip_comm_create failed: {e})"
-            ok = torch.tensor([1 if comm else 0], device=dev)
+            ok = torch.tensor([1 if all(sl.comm for sl in slots) else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if not int(ok.item()) and comm:
-                comm.close()
-                comm = None
-                gather_kind = "torch.distributed.gather over RCCL (a rank could not create the C-ABI communicator)"
+            if not int(ok.item()):
+                for sl in slots:
+                    if sl.comm:
+                        sl.comm.close()
+                    sl.comm = None
+                if "failed" not in (gather_kind or ""):
+                    gather_kind = "torch.distributed.gather over RCCL (a rank could not create the C-ABI communicator)"
         else:
             gather_kind = f"torch.distributed.gather over {backend} (rehearsal: ranks share a GPU, which RCCL refuses)"
+    use_comm = split and all(sl.comm for sl in slots)
 
     trace = bool(os.environ.get("RT_BENCH_TRACE"))     # debugging aid: synchronise and report after every frame
 
@@ -219,31 +246,38 @@ def main():
         return scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world((step_index * world + rank) % ORBIT_FRAMES, ORBIT_FRAMES))
 
     def step(i, flags=0):
+        sl = slots[i % n_slots]
         if sequence:
-            r.set_camera(camera_of(i))
-        r.render(flags, d_out=frame_local.data_ptr())
+            sl.r.set_camera(camera_of(i))
+        sl.r.render(flags, d_out=sl.frame_local.data_ptr())
         if trace:
-            r.sync()
+            sl.r.sync()
             print(f"[rank {rank}] frame rendered", file=sys.stderr, flush=True)
         if not split:
-            return frame_local
-        if comm:
-            comm.gather(frame_local, frame_full, sc.h, sc.w, rdist.BAND_H, 0, stream.cuda_stream)
-            return frame_full
-        return rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
+            return sl.frame_local
+        if use_comm:
+            sl.comm.gather(sl.frame_local, sl.frame_full, sc.h, sc.w, rdist.BAND_H, 0, sl.stream.cuda_stream)
+            return sl.frame_full
+        # torch's collective runs on torch's current stream: order it behind this slot's render
+        with torch.cuda.stream(sl.stream):
+            return rdist.gather_frame(sl.frame_local, sc.h, sc.w, rdist.BAND_H)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    if split and comm and args.warmup:
+    # (warm-up frames carry the timing flag too: the first timed frame of a context creates its events)
+    n_warm = max(args.warmup, n_slots if args.warmup else 0)
+    for i in range(n_warm):
+        step(i, RT_HIP_TIMING)
+    for sl in slots[:min(n_slots, n_warm)]:
+        sl.r.kernel_times()                        # discard the warm-up frames' timings
+    if use_comm and args.warmup:
         # the two gathers must agree (both outside the timed region)
         fence()
         want = rdist.gather_frame(frame_local, sc.h, sc.w, rdist.BAND_H)
-        if rank == 0 and not torch.equal(want, frame_full):
+        if rank == 0 and not all(torch.equal(want, sl.frame_full) for sl in slots):
             raise SystemExit("rt_hip_gather_frame and torch.distributed.gather assembled different frames")
     fence()
 
@@ -255,7 +289,20 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times, averaged over the timed steps (the events are
     # recorded on the stream the kernels run on); read after the timed region
-    kms, launches, wall = r.kernel_times_wall()
+    per_slot = [sl.r.kernel_times_wall() for sl in slots[:min(n_slots, args.steps)]]
+    launches = per_slot[0][1]
+    kms = {k: sum(p[0][k] for p in per_slot) / len(per_slot) for k in per_slot[0][0]}
+    wall = {k: sum(p[2][k] for p in per_slot) / len(per_slot) for k in per_slot[0][2]}
+
+    # one frame on its own (nothing else in flight): the latency of a frame, as opposed to the step time
+    lat = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r.render(0, d_out=frame_local.data_ptr())
+        r.sync()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    frame_latency_ms = sorted(lat)[len(lat) // 2]
 
     # rays of the timed steps (work-list counters; for a sequence every camera is rendered again, untimed)
     if sequence:
@@ -318,24 +365,28 @@ def main():
     if world == 1 and not sequence and not args.no_proxy:
         proxy = {}
         for parts in (2, 4, 8):
-            r.set_tile(rdist.BAND_H, parts, 0)
-            part_out = torch.zeros((rdist.padded_rows(sc.h, rdist.BAND_H, parts), sc.w, 4), dtype=torch.uint8, device=dev)
-            for _ in range(2):
-                r.render(0, d_out=part_out.data_ptr())
-            r.sync()
+            outs = []
+            for sl in slots:
+                sl.r.set_tile(rdist.BAND_H, parts, 0)
+                outs.append(torch.zeros((rdist.padded_rows(sc.h, rdist.BAND_H, parts), sc.w, 4), dtype=torch.uint8, device=dev))
+            for i in range(2 * n_slots):
+                slots[i % n_slots].r.render(0, d_out=outs[i % n_slots].data_ptr())
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(10):
-                r.render(0, d_out=part_out.data_ptr())
-            r.sync()
-            proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
-        r.set_tile(rdist.BAND_H, 1, 0)
+            for i in range(12):
+                slots[i % n_slots].r.render(0, d_out=outs[i % n_slots].data_ptr())
+            torch.cuda.synchronize()
+            proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 12 * 1e3, 4)
+        for sl in slots:
+            sl.r.set_tile(rdist.BAND_H, 1, 0)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / elapsed / 1e6
         if proxy is not None:
             proxy["full_frame_ms"] = round(ms_per_step, 4)
-            proxy["note"] = ("time of rank 0's share of an N-way band split of this frame on ONE GPU, render only (no exchange): "
+            proxy["note"] = ("step time of rank 0's share of an N-way band split of this frame on ONE GPU, scheduled as the timed "
+                             "region schedules the full frame (same frames in flight), render only (no exchange): "
                              "full_frame_ms / part_0_of_N_ms bounds the N-GPU speed-up from above")
         counters = committed_counters(args, dominant, world)
         out = {
@@ -354,6 +405,7 @@ def main():
                        "rays_per_step": int(rays_total / args.steps), "closest_rays_per_step": int(cnt[0] / args.steps),
                        "shadow_rays_per_step": int(cnt[1] / args.steps),
                        "frames_per_s": round(args.steps * (world if sequence else 1) / elapsed, 3),
+                       "frames_in_flight": n_slots, "frame_latency_ms_alone": round(frame_latency_ms, 4),
                        "parallelism": "single GPU" if world == 1 else
                                       (f"frame f of the sequence on rank f mod {world}, scene replicated, no exchange" if sequence else
                                        f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "
@@ -391,9 +443,11 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if comm:
-        comm.close()
-    r.close()
+    for sl in slots:
+        if sl.comm:
+            sl.comm.close()
+    for sl in reversed(slots):
+        sl.r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

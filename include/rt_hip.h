@@ -130,6 +130,12 @@ int  rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n );
 int  rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n );
 int  rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n );
 int  rt_hip_set_camera( rt_hip_ctx *c, const rt_camera *cam );
+/* Frames in flight (no reference counterpart: the reference blocks on every frame, rt_funcs_render_pipe.c:567-569):
+ * a second context on the same GPU, on its own stream, renders frame i + 1 while frame i of the first drains its
+ * sparse last passes.  It reads the tree, materials, spheres and lights of `from` (no copies: one working set in
+ * the caches); camera, image size, tile and parameters stay per context.  `from` must outlive every frame of `c`,
+ * and uploads into `from` must not run beside frames of `c`. */
+int  rt_hip_share_scene( rt_hip_ctx *c, const rt_hip_ctx *from );
 
 /* full image size; allocates the per-pixel work buffers */
 int  rt_hip_set_image( rt_hip_ctx *c, int w, int h );

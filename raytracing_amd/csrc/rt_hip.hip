@@ -2359,6 +2359,31 @@ int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle 
 	return 0;
 }
 
+// A second context on the same GPU that renders the same scene (frames in
+// flight: frame i + 1 starts on its own streams and work buffers while frame i
+// drains) reads the tree, materials, spheres and lights of `from` instead of
+// holding copies: one working set in the caches, not two.
+int rt_hip_share_scene( rt_hip_ctx *c, const rt_hip_ctx *from )
+{
+	if ( !c || !from || c == from ) return fail( "rt_hip_share_scene: bad arguments" );
+	if ( c->device != from->device ) return fail( "rt_hip_share_scene: contexts on different devices" );
+	if ( !from->S.nodes || !from->S.mats || !from->S.spheres || !from->S.lights ) return fail( "rt_hip_share_scene: the source context holds no complete scene" );
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	// own copies, if any, are released: the pointers below replace them
+	DevBuf *own[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights };
+	for ( DevBuf *b : own )
+		if ( b->p ) { HIPCHK( hipFree( b->p ) ); b->p = nullptr; b->cap = 0; }
+	c->S.nodes = from->S.nodes; c->S.recs = from->S.recs; c->S.shade = from->S.shade;
+	c->S.mats = from->S.mats; c->S.spheres = from->S.spheres; c->S.sphereMat = from->S.sphereMat; c->S.lights = from->S.lights;
+	c->S.nSpheres = from->S.nSpheres; c->S.nLights = from->S.nLights; c->S.alphaMonotone = from->S.alphaMonotone;
+	memcpy( c->S.bbC, from->S.bbC, sizeof( c->S.bbC ) );
+	memcpy( c->S.bbE, from->S.bbE, sizeof( c->S.bbE ) );
+	c->nNodes = from->nNodes; c->nRecs = from->nRecs; c->nTris = from->nTris; c->nMats = from->nMats;
+	c->maxMatTree = from->maxMatTree; c->maxMatSphere = from->maxMatSphere; c->treeDepth = from->treeDepth;
+	return 0;
+}
+
 int rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n )
 {
 	if ( !c || ( n && !m ) ) return fail( "rt_hip_upload_materials: bad arguments" );

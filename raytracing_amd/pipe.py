@@ -232,6 +232,14 @@ class HipRenderer:
         check(self._L.rt_hip_adopt_tree(self._c, C.byref(dtree._s)), "rt_hip_adopt_tree")
         dtree._s = None
 
+    def share_scene(self, other, scene):
+        """Render the scene resident in `other` (same GPU) without a copy of it: tree, materials, spheres, lights
+        are read from there; camera, image size and ray budget are set from `scene`."""
+        check(self._L.rt_hip_share_scene(self._c, other._c), "rt_hip_share_scene")
+        self.set_camera(scene.camera)
+        self.set_image(scene.w, scene.h)
+        self.set_param(RT_PARAM_STACK_SIZE, scene.stack_size)
+
     def load_scene(self, scene, tree=None, max_depth=10, max_prims=7, threads=0):
         """Upload everything `scene` holds; builds the tree unless given. -> tree"""
         if tree is None:

@@ -45,6 +45,7 @@ int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *v, const rt_triangle *t, 
 int rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n ) { c->sum += touch( m, n * sizeof( *m ) ); return 0; }
 int rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n ) { c->sum += touch( s, n * sizeof( *s ) ); return 0; }
 int rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n ) { c->sum += touch( l, n * sizeof( *l ) ); return 0; }
+int rt_hip_share_scene( rt_hip_ctx *, const rt_hip_ctx * ) { return 0; }
 int rt_hip_set_camera( rt_hip_ctx *c, const rt_camera *cam ) { c->sum += touch( cam, sizeof( *cam ) ); return 0; }
 int rt_hip_set_image( rt_hip_ctx *c, int w, int h ) { c->w = w; c->h = h; return w < 2 || h < 2; }
 int rt_hip_set_tile( rt_hip_ctx *c, int bandH, int parts, int part ) { c->bandH = bandH; c->parts = parts; c->part = part; return 0; }

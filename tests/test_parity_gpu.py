@@ -875,3 +875,55 @@ def test_two_contexts_interleaved_and_from_two_threads():
     for i in range(2):
         assert out[i] is not None
         assert np.array_equal(out[i][0], alone[i][0]) and np.array_equal(out[i][1], alone[i][1])
+
+
+def test_frames_in_flight_on_contexts_that_share_one_scene():
+    """Two contexts on streams of their own render the scene resident in the
+    first (rt_hip_share_scene: no second copy of tree, materials, lights), each
+    with its own camera, frames enqueued alternately without synchronisation in
+    between.  Every frame is the one the scene gives on its own for that camera."""
+    import torch
+    sc = scenes.sphere_scene(100, 80, 256, 160, reflect=0.5)
+    cams = []
+    for k in range(2):
+        cam = sc.camera.copy()
+        cam["world"][3, 0] += np.float32(6.0 * k)          # row 3 of the world matrix is the eye
+        cam["world"][3, 1] -= np.float32(4.0 * k)
+        cams.append(cam)
+    alone = []
+    for cam in cams:
+        sc.camera = cam
+        img, ids, _, tree = hip_render(sc, 18, 7, flags=RT_HIP_HITIDS)
+        tree.release()
+        alone.append((img, ids))
+    assert not np.array_equal(alone[0][0], alone[1][0])
+
+    v, t = sc.flatten()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    first = HipRenderer(0, stream=streams[0].cuda_stream)
+    sc.camera = cams[0]
+    first.load_scene(sc, FlatTree.build(v, t, 18, 7))
+    second = HipRenderer(0, stream=streams[1].cuda_stream)
+    sc.camera = cams[1]
+    second.share_scene(first, sc)
+    outs = [torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(4):
+        for r, o in zip((first, second), outs):
+            r.render(RT_HIP_HITIDS, d_out=o.data_ptr())
+    for r, o, (img, ids) in zip((first, second), outs, alone):
+        r.sync()
+        assert np.array_equal(o.cpu().numpy(), img)          # (a frame given a destination is written there only)
+        assert np.array_equal(r.read_hit_ids(), ids)
+    # the borrower goes first; the owner's scene is still whole afterwards
+    second.close()
+    first.render(RT_HIP_HITIDS)
+    assert np.array_equal(first.read_frame(), alone[0][0])
+    first.close()
+    with pytest.raises(Exception, match="share_scene"):
+        a, b = HipRenderer(0), HipRenderer(0)
+        try:
+            a.share_scene(b, sc)          # b holds no scene
+        finally:
+            a.close()
+            b.close()
