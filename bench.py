@@ -73,6 +73,17 @@ def algorithmic_bytes(nodes, tris, primary, hits):
     return 8 * nodes + 48 * tris + 4 * primary + 128 * hits
 
 
+def union_length(spans):
+    """Total length covered by a list of (start, end) intervals."""
+    total, end = 0.0, float("-inf")
+    for a, b in sorted(spans):
+        lo = max(a, end)
+        if b > lo:
+            total += b - lo
+            end = b
+    return total
+
+
 def committed_counters(args, kernel, world):
     """What the committed rocprofv3 counter passes of this same frame say about
     `kernel` (profiles/r02_counters.json, written by tools/refresh_profiles.py:
@@ -289,10 +300,17 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times, averaged over the timed steps (the events are
     # recorded on the stream the kernels run on); read after the timed region
-    per_slot = [sl.r.kernel_times_wall() for sl in slots[:min(n_slots, args.steps)]]
+    used = slots[:min(n_slots, args.steps)]
+    # wall-clock time per step during which a kernel had at least one launch running, over ALL frames in flight
+    # (launch intervals of every slot on one clock; the union never exceeds the timed region)
+    spans = {}
+    for sl in used:
+        for kind, a, b in sl.r.kernel_intervals(origin=used[0].r):
+            spans.setdefault(kind, []).append((a, b))
+    wall = {k: union_length(v) / args.steps for k, v in spans.items() if k != "frame"}
+    per_slot = [sl.r.kernel_times_wall() for sl in used]
     launches = per_slot[0][1]
     kms = {k: sum(p[0][k] for p in per_slot) / len(per_slot) for k in per_slot[0][0]}
-    wall = {k: sum(p[2][k] for p in per_slot) / len(per_slot) for k in per_slot[0][2]}
 
     # one frame on its own (nothing else in flight): the latency of a frame, as opposed to the step time
     lat = []
@@ -412,18 +430,21 @@ def main():
                                        f"rows gathered on rank 0: {gather_kind}")},
             # sums of launch durations (launches that run side by side add up: can exceed the frame time)
             "kernel_ms_per_frame_rank0": {k: round(x, 4) for k, x in kms.items()},
-            # wall-clock time during which at least one launch of the kernel ran (never exceeds the frame time)
+            # wall-clock time per step during which at least one launch of the kernel ran, all frames in flight
+            # taken together (never exceeds ms_per_step)
             "kernel_wall_ms_per_frame_rank0": {k: round(x, 4) for k, x in wall.items()},
             "kernel_ms_per_frame_isolated_rank0": {k: round(x, 4) for k, x in kms_iso.items()},
             "roofline": {"bound": "hbm", "kernel": "k_" + dominant,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": counters.get("fabric_bytes_per_launch") if counters else None,
-                         "time_basis": "wall-attributed: algorithmic bytes of the kernel's launches of one frame / the time during "
-                                       "which at least one of them ran (HIP events on the streams they run on, timed region)",
+                         "time_basis": "wall-attributed: algorithmic bytes of the kernel's launches of one frame / the time per step "
+                                       "during which at least one launch of the kernel ran, over all frames in flight (HIP events "
+                                       "on the streams they run on, timed region, one clock)",
                          "launches_per_frame": n_launch,
                          "algorithmic_bytes_per_launch": int(dom_bytes / n_launch),
                          "avg_launch_ms": round(kms[dominant] / n_launch, 4),
+                         "avg_launch_ms_wall": round(wall[dominant] / n_launch, 4),
                          "avg_launch_ms_isolated": round(kms_iso[dominant] / n_launch, 4),
                          "achieved_isolated": round(gbs(dom_bytes, kms_iso[dominant]), 2),
                          # the working set (0.26 GB) is served by L2 and the Infinity Cache, so these are the roofs that can bind

@@ -198,6 +198,13 @@ int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );
  * least one of its launches was running (length of the union of its launch intervals).  Unlike ms[], which adds up
  * launches that run side by side, wall[] never exceeds the frame time. */
 int  rt_hip_kernel_times_ex( rt_hip_ctx *c, float ms[5], int launches[5], float wall[4] );
+/* Every launch of the frames rendered with RT_HIP_TIMING since the last rt_hip_kernel_times[_ex] call, as
+ * an interval startEnd[2 i], startEnd[2 i + 1] in ms after the start of the oldest such frame of `origin` (a
+ * context on the same GPU, NULL = c): contexts that keep frames in flight side by side come onto one clock, and
+ * the union of a kernel's intervals over all of them is the wall-clock time that kernel had work on the chip.
+ * kind[i]: 0 closest-hit, 1 shadow, 2 lighting, 3 fold, 4 the whole frame.  Needs room (cap) for
+ * frames * (3 * slots + 2) intervals; *count = intervals written.  Leaves the timings in place. */
+int  rt_hip_kernel_intervals( rt_hip_ctx *c, rt_hip_ctx *origin, float *startEnd, int *kind, int cap, int *count );
 /* Device self-test (no reference counterpart): the triangle test replaces the
  * IEEE division 1 / det by a hardware reciprocal plus one Newton step where
  * that is exact.  Evaluates both for all 2^32 float bit patterns; *mismatches

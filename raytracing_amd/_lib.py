@@ -105,7 +105,7 @@ def lib():
         L.rt_render_pipe_draw.restype = C.c_void_p
         for name in ("rt_hip_set_stream", "rt_hip_upload_tree", "rt_hip_upload_materials",
                      "rt_hip_upload_spheres", "rt_hip_upload_lights", "rt_hip_set_camera",
-                     "rt_hip_set_image", "rt_hip_set_tile", "rt_hip_share_scene", "rt_hip_render_noalloc", "rt_hip_kernel_times_ex", "rt_hip_local_rows", "rt_hip_set_param",
+                     "rt_hip_set_image", "rt_hip_set_tile", "rt_hip_share_scene", "rt_hip_render_noalloc", "rt_hip_kernel_times_ex", "rt_hip_kernel_intervals", "rt_hip_local_rows", "rt_hip_set_param",
                      "rt_hip_render", "rt_hip_sync", "rt_hip_read_frame", "rt_hip_read_hit_ids",
                      "rt_hip_get_stats", "rt_hip_kernel_times", "rt_kdtree_build_flat", "rt_kdtree_build_flat_ex",
                      "rt_kdtree_flat_expand", "rt_kdtree_flatten", "rt_hip_device_count"):

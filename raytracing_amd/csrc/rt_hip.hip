@@ -2956,6 +2956,49 @@ int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 	return rt_hip_kernel_times_ex( c, ms, launches, nullptr );
 }
 
+// Every launch of the frames rendered with RT_HIP_TIMING since the last read-out, as an interval
+// [start, end] in milliseconds after the start of the oldest such frame of `origin` (a context on
+// the same GPU; `c` itself when null): contexts that render frames side by side are brought onto
+// one clock, so a caller can take the union of a kernel's intervals over all of them.
+// kind: 0 closest, 1 shadow, 2 light, 3 fold, 4 whole frame.  Does not reset the timings.
+int rt_hip_kernel_intervals( rt_hip_ctx *c, rt_hip_ctx *origin, float *startEnd, int *kind, int cap, int *count )
+{
+	if ( !c || !startEnd || !kind || !count || cap < 0 ) return fail( "rt_hip_kernel_intervals: bad arguments" );
+	if ( !origin ) origin = c;
+	if ( c->device != origin->device ) return fail( "rt_hip_kernel_intervals: contexts on different devices" );
+	if ( c->timedFrames == 0 || origin->timedFrames == 0 )
+		return fail( "rt_hip_kernel_intervals: no frame was rendered with RT_HIP_TIMING since the last read-out" );
+	HIPCHK( hipSetDevice( c->device ) );
+	HIPCHK( hipStreamSynchronize( c->stream ) );
+	HIPCHK( hipStreamSynchronize( origin->stream ) );
+	const int kept = origin->timedFrames < RT_TIMED_FRAMES ? origin->timedFrames : RT_TIMED_FRAMES;
+	hipEvent_t zero = origin->ev[( origin->timedFrames - kept ) % RT_TIMED_FRAMES][6 * RT_MAX_SLOTS + 2];
+	const int n = c->timedSlots;
+	const int frames = c->timedFrames < RT_TIMED_FRAMES ? c->timedFrames : RT_TIMED_FRAMES;
+	if ( frames * ( 3 * n + 2 ) > cap ) return fail( "rt_hip_kernel_intervals: room for %d intervals, %d needed", cap, frames * ( 3 * n + 2 ) );
+	int m = 0;
+	auto put = [&]( hipEvent_t a, hipEvent_t b, int what ) -> int
+	{
+		float t0 = 0.0f, dt = 0.0f;
+		HIPCHK( hipEventElapsedTime( &t0, zero, a ) );
+		HIPCHK( hipEventElapsedTime( &dt, a, b ) );
+		startEnd[2 * m] = t0; startEnd[2 * m + 1] = t0 + dt; kind[m] = what;
+		++m;
+		return 0;
+	};
+	for ( int f = frames - 1; f >= 0; --f )
+	{
+		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
+		for ( int k = 0; k < n; ++k )
+			for ( int j = 0; j < 3; ++j )
+				if ( put( ev[6 * k + 2 * j], ev[6 * k + 2 * j + 1], j ) ) return 1;
+		if ( put( ev[6 * RT_MAX_SLOTS], ev[6 * RT_MAX_SLOTS + 1], 3 ) ) return 1;
+		if ( put( ev[6 * RT_MAX_SLOTS + 2], ev[6 * RT_MAX_SLOTS + 3], 4 ) ) return 1;
+	}
+	*count = m;
+	return 0;
+}
+
 int rt_hip_kernel_times_ex( rt_hip_ctx *c, float ms[5], int launches[5], float wall[4] )
 {
 	if ( !c || !ms || !launches ) return fail( "rt_hip_kernel_times: bad arguments" );

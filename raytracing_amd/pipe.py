@@ -265,11 +265,33 @@ class HipRenderer:
     def sync(self):
         check(self._L.rt_hip_sync(self._c), "rt_hip_sync")
 
-    def read_frame(self):
-        """-> uint8 [local_rows, w, 4] in b,g,r,a order"""
-        out = np.zeros((self.local_rows, self.w, 4), np.uint8)
+    def read_frame(self, out=None):
+        """-> uint8 [local_rows, w, 4] in b,g,r,a order (into `out` when given: same shape, contiguous)"""
+        if out is None:
+            out = np.zeros((self.local_rows, self.w, 4), np.uint8)
+        elif out.shape != (self.local_rows, self.w, 4) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise RtError("read_frame: `out` must be a contiguous uint8 array of shape (local_rows, w, 4)")
         check(self._L.rt_hip_read_frame(self._c, _p(out)), "rt_hip_read_frame")
         return out
+
+    def alloc_host_frame(self):
+        """A page-locked uint8 [local_rows, w, 4] block for read_frame(out=...): read-backs into it run at link speed
+        and need no staging copy.  Stays valid until free_host_frame() or close()."""
+        n = self.local_rows * self.w * 4
+        self._L.rt_hip_alloc_host.restype = C.c_void_p
+        self._L.rt_hip_alloc_host.argtypes = [C.c_void_p, C.c_size_t]
+        p = self._L.rt_hip_alloc_host(self._c, n)
+        if not p:
+            raise RtError("rt_hip_alloc_host: " + self._L.rt_hip_last_error().decode())
+        a = np.frombuffer((C.c_uint8 * n).from_address(p), np.uint8).reshape(self.local_rows, self.w, 4)
+        self._host_blocks = getattr(self, "_host_blocks", {})
+        self._host_blocks[a.ctypes.data] = p
+        return a
+
+    def free_host_frame(self, a):
+        p = self._host_blocks.pop(a.ctypes.data)
+        self._L.rt_hip_free_host.argtypes = [C.c_void_p, C.c_void_p]
+        self._L.rt_hip_free_host(self._c, C.c_void_p(p))
 
     def read_hit_ids(self):
         out = np.zeros((self.local_rows, self.w), np.int32)
@@ -298,6 +320,18 @@ class HipRenderer:
         names = ("closest", "shadow", "shade", "fold", "frame")
         return (dict(zip(names, [float(x) for x in ms])), dict(zip(names, [int(x) for x in n])),
                 dict(zip(names[:4], [float(x) for x in wall])))
+
+    def kernel_intervals(self, origin=None):
+        """[(kind, start_ms, end_ms)] of every launch of the timed frames since the last kernel_times*() call, on the
+        clock of `origin` (a renderer on the same GPU; default: this one).  kind: closest, shadow, shade, fold, frame."""
+        cap = 32 * (3 * 8 + 2)
+        iv = (C.c_float * (2 * cap))()
+        kind = (C.c_int * cap)()
+        n = C.c_int(0)
+        check(self._L.rt_hip_kernel_intervals(self._c, origin._c if origin is not None else None, iv, kind, cap, C.byref(n)),
+              "rt_hip_kernel_intervals")
+        names = ("closest", "shadow", "shade", "fold", "frame")
+        return [(names[kind[i]], float(iv[2 * i]), float(iv[2 * i + 1])) for i in range(n.value)]
 
     def selftest_rcp(self):
         """(mismatches, fast-path inputs) of the exact-reciprocal shortcut over all 2^32 floats."""

@@ -67,6 +67,7 @@ void rt_hip_free_host( rt_hip_ctx *, void * ) {}
 int rt_hip_get_stats( rt_hip_ctx *, rt_hip_stats * ) { return 1; }
 int rt_hip_kernel_times( rt_hip_ctx *, float *, int * ) { return 1; }
 int rt_hip_kernel_times_ex( rt_hip_ctx *, float *, int *, float * ) { return 1; }
+int rt_hip_kernel_intervals( rt_hip_ctx *, rt_hip_ctx *, float *, int *, int, int * ) { return 1; }
 int rt_hip_selftest_rcp( rt_hip_ctx *, uint64_t *, uint64_t * ) { return 1; }
 
 // GPU kd builder (kd_build_gpu.hip): not available in this build

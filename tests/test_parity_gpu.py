@@ -487,17 +487,59 @@ def test_fly_through_frames_match_the_oracle(frame):
     tree.release()
 
 
-def test_fly_through_driver_single_rank(tmp_path):
+def _read_png(path):
+    """Decoder for the files apps/flythrough.py writes (8-bit RGB, filter type 0 on every row)."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data)
+        if tag == b"IHDR":
+            w, h = struct.unpack(">II", data[:8])
+        elif tag == b"IDAT":
+            idat += data
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert not rows[:, 0].any()
+    return rows[:, 1:].reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("mode", ["pipelined", "serial"])
+def test_fly_through_driver_single_rank(tmp_path, mode):
+    """Frames in flight + encoder threads (and the one-at-a-time mode) write, for every camera of the orbit, the
+    frame that camera gives when rendered on its own."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "apps", "flythrough.py"), "--frames", "3", "--size", "160x96",
-                          "--lon", "40", "--lat", "20", "--depth", "14", "--leaf", "7", "--out", str(tmp_path / "pngs")],
+    n = 5
+    cmd = [sys.executable, os.path.join(root, "apps", "flythrough.py"), "--frames", str(n), "--size", "160x96",
+           "--lon", "40", "--lat", "20", "--depth", "14", "--leaf", "7", "--out", str(tmp_path / "pngs")]
+    out = subprocess.run(cmd + (["--serial"] if mode == "serial" else ["--encoders", "3"]),
                          check=True, capture_output=True, text=True, timeout=300).stdout
     rec = json.loads(out.strip().splitlines()[-1])
-    assert rec["frames"] == 3 and rec["rays_last_frame"] > 160 * 96
-    assert sorted(os.listdir(tmp_path / "pngs")) == ["10.png", "8.png", "9.png"]
+    assert rec["frames"] == n and rec["rays_last_frame"] > 160 * 96
+    assert rec["frames_in_flight"] == (1 if mode == "serial" else 2)
+    assert sorted(os.listdir(tmp_path / "pngs"), key=lambda x: int(x[:-4])) == [f"{f + 8}.png" for f in range(n)]
+    sc = scenes.config5_frame(0, 160, 96, 40, 20)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 14, 7)
+    r = HipRenderer(0)
+    r.load_scene(sc, tree)
+    seen = []
+    for f in range(n):
+        r.set_camera(scenes.make_camera(160, 96, world=scenes.orbit_world(f, n)))
+        r.render(0)
+        want = r.read_frame()[..., [2, 1, 0]]
+        assert np.array_equal(_read_png(tmp_path / "pngs" / f"{f + 8}.png"), want), f"frame {f}"
+        seen.append(want)
+    r.close()
+    tree.release()
+    assert not np.array_equal(seen[0], seen[1])
 
 
 def _soup_scene(seed, n_tris, alphas, w=128, h=96):

@@ -3,13 +3,14 @@
 #   bench.json / bench.err     the default bench.py line
 #   stats/                     rocprofv3 --kernel-trace --stats of the same command
 #   pmc/                       counter passes (one rocprofv3 run each) over a short run of the same frame
-# Usage: tools/profile_round.sh <tag>
+#   pmc_serial/                the same with every pass alone on the chip (RT_OVERLAP=0)
+# Usage: tools/profile_round.sh <tag> ; then, here: python tools/refresh_profiles.py <tag> <round, e.g. r02>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 export PYTHONPATH=. TMPDIR=/tmp
 mkdir -p $OUT
-timeout -k 10 400 python3 -u bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+timeout -k 10 500 python3 -u bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo bench done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo stats done
