@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--leaf", type=int, default=TREE_LEAF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy (1-GPU runs of a frame workload)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="for profiler runs: every launch of the frame kernels belongs to the warm-up or the timed steps (no "
+                         "frame-alone latency, no in-order pass, no proxy), so a profiler's per-kernel average is the timed "
+                         "region's avg_launch_ms")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -314,13 +318,13 @@ def main():
 
     # one frame on its own (nothing else in flight): the latency of a frame, as opposed to the step time
     lat = []
-    for _ in range(5):
+    for _ in range(0 if args.timed_only else 5):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         r.render(0, d_out=frame_local.data_ptr())
         r.sync()
         lat.append((time.perf_counter() - t1) * 1e3)
-    frame_latency_ms = sorted(lat)[len(lat) // 2]
+    frame_latency_ms = sorted(lat)[len(lat) // 2] if lat else float("nan")
 
     # rays of the timed steps (work-list counters; for a sequence every camera is rendered again, untimed)
     if sequence:
@@ -347,12 +351,14 @@ def main():
     # that the normal schedule runs beside it)
     if sequence:
         r.set_camera(camera_of(args.warmup))
-    r.set_param(RT_PARAM_OVERLAP, 0)
-    for _ in range(3):
-        r.render(RT_HIP_TIMING, d_out=frame_local.data_ptr())
-    r.sync()
-    kms_iso, _ = r.kernel_times()
-    r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
+    kms_iso = None
+    if not args.timed_only:
+        r.set_param(RT_PARAM_OVERLAP, 0)
+        for _ in range(3):
+            r.render(RT_HIP_TIMING, d_out=frame_local.data_ptr())
+        r.sync()
+        kms_iso, _ = r.kernel_times()
+        r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
 
     # ---- roofline of the dominant kernel (counting pass, outside the timed region)
     r.render(RT_HIP_STATS, d_out=frame_local.data_ptr())
@@ -380,7 +386,7 @@ def main():
 
     # ---- strong-scaling proxy: what one rank of an N-GPU split of this frame takes on this GPU
     proxy = None
-    if world == 1 and not sequence and not args.no_proxy:
+    if world == 1 and not sequence and not args.no_proxy and not args.timed_only:
         proxy = {}
         for parts in (2, 4, 8):
             outs = []
@@ -423,7 +429,7 @@ def main():
                        "rays_per_step": int(rays_total / args.steps), "closest_rays_per_step": int(cnt[0] / args.steps),
                        "shadow_rays_per_step": int(cnt[1] / args.steps),
                        "frames_per_s": round(args.steps * (world if sequence else 1) / elapsed, 3),
-                       "frames_in_flight": n_slots, "frame_latency_ms_alone": round(frame_latency_ms, 4),
+                       "frames_in_flight": n_slots, "frame_latency_ms_alone": round(frame_latency_ms, 4) if lat else None,
                        "parallelism": "single GPU" if world == 1 else
                                       (f"frame f of the sequence on rank f mod {world}, scene replicated, no exchange" if sequence else
                                        f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "
@@ -433,7 +439,7 @@ def main():
             # wall-clock time per step during which at least one launch of the kernel ran, all frames in flight
             # taken together (never exceeds ms_per_step)
             "kernel_wall_ms_per_frame_rank0": {k: round(x, 4) for k, x in wall.items()},
-            "kernel_ms_per_frame_isolated_rank0": {k: round(x, 4) for k, x in kms_iso.items()},
+            "kernel_ms_per_frame_isolated_rank0": {k: round(x, 4) for k, x in kms_iso.items()} if kms_iso else None,
             "roofline": {"bound": "hbm", "kernel": "k_" + dominant,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -445,8 +451,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(dom_bytes / n_launch),
                          "avg_launch_ms": round(kms[dominant] / n_launch, 4),
                          "avg_launch_ms_wall": round(wall[dominant] / n_launch, 4),
-                         "avg_launch_ms_isolated": round(kms_iso[dominant] / n_launch, 4),
-                         "achieved_isolated": round(gbs(dom_bytes, kms_iso[dominant]), 2),
+                         "avg_launch_ms_isolated": round(kms_iso[dominant] / n_launch, 4) if kms_iso else None,
+                         "achieved_isolated": round(gbs(dom_bytes, kms_iso[dominant]), 2) if kms_iso else None,
                          # the working set (0.26 GB) is served by L2 and the Infinity Cache, so these are the roofs that can bind
                          "frac_of_l2_roof": round(achieved / L2_PEAK_GBS, 5), "l2_peak": L2_PEAK_GBS,
                          "frac_of_infinity_cache_roof": round(achieved / MALL_PEAK_GBS, 5), "infinity_cache_peak": MALL_PEAK_GBS,

@@ -97,6 +97,10 @@
 #ifndef RT_COOP_LIVE
 #define RT_COOP_LIVE 32
 #endif
+// triangles of a leaf a lane scans per round of the lane-per-ray walk
+#ifndef RT_LEAF_STEP
+#define RT_LEAF_STEP 0x7fffffff
+#endif
 #ifndef RT_COOP_MIN_SHIFT
 #define RT_COOP_MIN_SHIFT 2u
 #endif
@@ -170,6 +174,7 @@ struct Work
 	uint2  *spill;                        // traversal stack overflow
 	uint32_t coopLive;                    // lanes still walking at which a wave goes over to the cooperative walk (0 = never)
 	uint32_t coopCap;                     // stack entries per ray the cooperative walk may use (<= RT_LDS_STACK; less only in tests)
+	uint32_t leafStep;                    // triangles of a leaf a lane scans per round (the rest waits for the next round)
 	uint32_t npix, tilesX, nChunks0, spillStride;
 	uint32_t cap;                         // entries per ray list / hit list (npix + room for reservation holes)
 };
@@ -661,9 +666,10 @@ DEVI void nearest_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, uin
 	}
 	if ( lane_id() == owner )
 	{
-		lt = best;
-		if ( found )
+		// lt: what an earlier round found in the first part of this leaf (strictly smaller wins)
+		if ( found && best < lt )
 		{
+			lt = best;
 			h.minU = bu;
 			h.minV = bv;
 			h.prN = bid;
@@ -1226,17 +1232,19 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 // keep their own lane, and the gear change waits for them.
 template <bool STATS>
 DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl,
-	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
+	uint32_t coopLive, uint32_t coopCap, bool atOnce, uint32_t step PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	// the cooperative walk is the last thing a chunk does (nothing of the lane-per-ray
 	// walk stays live across it): rays parallel to an axis are finished first
 	const bool ownLane = coopLive == 0u || axis_parallel( r );
 	bool walked = atOnce;
+	float lt = INFINITY;
 	while ( __ballot( live ) != 0ull )
 	{
 		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && ownLane ) == 0ull )
 		{
+			// (a lane that is part-way through a leaf starts that leaf again: same minimum)
 			PROF_T0( pc );
 			nearest_coop<STATS>( S, r, live, t, h, tl, coopCap PROF_PASS );
 			PROF_ADD( tCoop, pc );
@@ -1244,7 +1252,9 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 		}
 		walked = true;
 		PROF_INC( lock );
-		float lt = INFINITY;
+		// A lane scans at most `step` triangles of its leaf per round and keeps the rest
+		// (t.n = first record / count still to scan, lt = the minimum so far) for the
+		// next one: a long leaf does not hold up the lanes that are through theirs.
 		uint32_t cnt = 0u;
 		if ( live )
 		{
@@ -1262,6 +1272,7 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 			// Two records are kept in flight and take turns (no register copies); the
 			// array ends with one spare record, so the look-ahead load of the last
 			// triangle stays inside the buffer.
+			if ( cnt > step ) cnt = step;
 			uint32_t i = t.n.x;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
@@ -1277,11 +1288,19 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 		}
 		if ( live )
 		{
-			h.minT = lt;
-			if ( h.nearestB && ( h.minT < t.tFar ) )
-				live = false;
-			else
-				live = trav_pop<STATS>( S, st, t, tl );
+			t.n.x += cnt;
+			t.n.y -= cnt << 2;
+			if ( ( t.n.y >> 2 ) == 0u )
+			{
+				h.minT = lt;
+				if ( h.nearestB && ( h.minT < t.tFar ) )
+					live = false;
+				else
+				{
+					live = trav_pop<STATS>( S, st, t, tl );
+					lt = INFINITY;
+				}
+			}
 		}
 	}
 }
@@ -1289,7 +1308,7 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 // shadow query of every lane with `live` set, CL/rt_funcs_primitives.cl:295-378
 template <bool STATS>
 DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, float d, float &alpha, Tally &tl,
-	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
+	uint32_t coopLive, uint32_t coopCap, bool atOnce, uint32_t step PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	const bool ownLane = coopLive == 0u || axis_parallel( r );
@@ -1317,6 +1336,8 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 		}
 		else if ( live && cnt != 0u )
 		{
+			// at most `step` triangles per round, the rest of the leaf in the next one (see nearest_wave)
+			if ( cnt > step ) cnt = step;
 			uint32_t i = t.n.x;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
@@ -1332,11 +1353,13 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 		}
 		if ( live )
 		{
+			t.n.x += cnt;
+			t.n.y -= cnt << 2;
 			// the caller clamps the sum to [0,1]: with non-negative opacities it
 			// cannot drop below 1 again, the rest of the ray is irrelevant
 			if ( S.alphaMonotone && alpha >= 1.0f )
 				live = false;
-			else
+			else if ( ( t.n.y >> 2 ) == 0u )
 				live = trav_pop<STATS>( S, st, t, tl );
 		}
 	}
@@ -1757,7 +1780,7 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull };
 		const unsigned long long c0 = wall_clock64();
 #endif
-		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
+		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ), W.leafStep PROF_PASS );
 		finish_closest( S, W, slot, wantIds, out, valid, e, rh, h, sph );
 #ifdef RT_PROFILE_CHUNKS
 		if ( lane_id() == 0u )
@@ -1867,7 +1890,7 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScen
 #ifdef RT_PROFILE_CHUNKS
 		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull };
 #endif
-		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
+		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ), W.leafStep PROF_PASS );
 		if ( item )
 			W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
@@ -2076,6 +2099,7 @@ struct rt_hip_ctx
 	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
 	int gridShadow[2] = { 0, 0 }, gridLight = 0;
 	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK, coopFill = 8, coopAtOnce = 0;
+	int leafStep = RT_LEAF_STEP, leafStepShadow = RT_LEAF_STEP;
 	uint32_t bigFrame = RT_BIG_FRAME;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[RT_AUX_STREAMS] = {};        // shadow + lighting passes (slot k on stream k mod RT_AUX_STREAMS)
@@ -2193,6 +2217,8 @@ rt_hip_ctx *rt_hip_create( int device )
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
 	}
 	// development knob
+	if ( const char *v = getenv( "RT_LEAF_STEP" ) ) c->leafStep = c->leafStepShadow = atoi( v ) > 0 ? atoi( v ) : RT_LEAF_STEP;
+	if ( const char *v = getenv( "RT_LEAF_STEP_SHADOW" ) ) c->leafStepShadow = atoi( v ) > 0 ? atoi( v ) : RT_LEAF_STEP;
 	if ( const char *v = getenv( "RT_COOP_LIVE" ) ) c->coopLive = atoi( v );
 	if ( c->coopLive < 0 || c->coopLive > 32 ) c->coopLive = 0;
 	if ( const char *v = getenv( "RT_COOP_FILL" ) ) c->coopFill = atoi( v ) > 0 && atoi( v ) < 256 ? atoi( v ) : 8;
@@ -2651,6 +2677,7 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + k % RT_AUX_STREAMS ) * W.spillStride * RT_SPILL_CAP;
 		Wx.coopLive = c->coopShadow && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wx.coopCap = (uint32_t) c->coopCap;
+		Wx.leafStep = (uint32_t) c->leafStepShadow;
 
 		// a persistent grid never needs more waves than there are chunks
 		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
@@ -2674,6 +2701,7 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		Work Wc = W;
 		Wc.coopLive = c->coopClosest && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wc.coopCap = (uint32_t) c->coopCap;
+		Wc.leafStep = (uint32_t) c->leafStep;
 		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, Wc, k, ids ? 1 : 0 );
 		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
 		if ( overlap )

@@ -12,7 +12,7 @@ export PYTHONPATH=. TMPDIR=/tmp
 mkdir -p $OUT
 timeout -k 10 500 python3 -u bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo bench done
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline --timed-only > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo stats done
 tools/pmc_passes.sh $OUT/pmc || exit 1
 RT_OVERLAP=0 tools/pmc_passes.sh $OUT/pmc_serial || exit 1
