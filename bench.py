@@ -230,27 +230,41 @@ def main():
     # start, and the JSON line says which
     gather_kind = None
     if split:
-        if backend == "nccl":
+        if backend == "nccl" and os.environ.get("RT_BENCH_GATHER", "abi") != "torch":
+            # Opening a communicator is a collective: a rank that cannot take part (no RCCL library to open) must be
+            # known BEFORE the others enter it, or they would wait for it for ever.  So every rank first asks the
+            # library for an id (that opens RCCL and calls into it, nothing collective), and all ranks compare notes.
+            why = ""
             try:
+                rdist.HipComm.unique_id()
+            except Exception as e:                                     # noqa: BLE001 - reported in the JSON line
+                why = str(e)
+            ok = torch.tensor([0 if why else 1], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
                 for sl in slots:
                     idt = torch.zeros(rdist.HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
                     if rank == 0:
                         idt.copy_(torch.frombuffer(bytearray(rdist.HipComm.unique_id()), dtype=torch.uint8))
                     dist.broadcast(idt, 0)
-                    sl.comm = rdist.HipComm(local_dev, world, rank, bytes(idt.cpu().numpy().tobytes()))
+                    try:
+                        sl.comm = rdist.HipComm(local_dev, world, rank, bytes(idt.cpu().numpy().tobytes()))
+                    except Exception as e:                             # noqa: BLE001
+                        why = str(e)
                     sl.frame_full = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+                ok = torch.tensor([1 if all(sl.comm for sl in slots) else 0], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
                 gather_kind = "rt_hip_gather_frame (C-ABI: RCCL send/receive to rank 0 + de-interleave kernel)"
-            except Exception as e:                                     # noqa: BLE001 - reported in the JSON line
-                gather_kind = f"torch.distributed.gather over RCCL (rt_hip_comm_create failed: {e})"
-            ok = torch.tensor([1 if all(sl.comm for sl in slots) else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if not int(ok.item()):
+            else:
                 for sl in slots:
                     if sl.comm:
                         sl.comm.close()
                     sl.comm = None
-                if "failed" not in (gather_kind or ""):
-                    gather_kind = "torch.distributed.gather over RCCL (a rank could not create the C-ABI communicator)"
+                gather_kind = ("torch.distributed.gather over RCCL (the C-ABI communicator could not be opened on every rank"
+                               + (f"; this rank: {why}" if why else "") + ")")
+        elif backend == "nccl":
+            gather_kind = "torch.distributed.gather over RCCL (RT_BENCH_GATHER=torch)"
         else:
             gather_kind = f"torch.distributed.gather over {backend} (rehearsal: ranks share a GPU, which RCCL refuses)"
     use_comm = split and all(sl.comm for sl in slots)

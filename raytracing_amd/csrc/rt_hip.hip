@@ -97,10 +97,6 @@
 #ifndef RT_COOP_LIVE
 #define RT_COOP_LIVE 32
 #endif
-// triangles of a leaf a lane scans per round of the lane-per-ray walk
-#ifndef RT_LEAF_STEP
-#define RT_LEAF_STEP 0x7fffffff
-#endif
 #ifndef RT_COOP_MIN_SHIFT
 #define RT_COOP_MIN_SHIFT 2u
 #endif
@@ -149,6 +145,7 @@ struct Counters
 	uint32_t chunkHist[RT_MAX_SLOTS][64];
 	unsigned long long lockRounds[RT_MAX_SLOTS], coopRounds[RT_MAX_SLOTS], coopIters[RT_MAX_SLOTS], chunksSeen[RT_MAX_SLOTS];
 	unsigned long long tExpand[RT_MAX_SLOTS], tScan[RT_MAX_SLOTS], tCoop[RT_MAX_SLOTS], tChunk[RT_MAX_SLOTS];
+	unsigned long long tDescend[RT_MAX_SLOTS], tLeaf[RT_MAX_SLOTS], tFinish[RT_MAX_SLOTS], tSetup[RT_MAX_SLOTS];
 	uint32_t maxLock[RT_MAX_SLOTS], maxCoop[RT_MAX_SLOTS], maxIters[RT_MAX_SLOTS];
 #endif
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
@@ -174,7 +171,6 @@ struct Work
 	uint2  *spill;                        // traversal stack overflow
 	uint32_t coopLive;                    // lanes still walking at which a wave goes over to the cooperative walk (0 = never)
 	uint32_t coopCap;                     // stack entries per ray the cooperative walk may use (<= RT_LDS_STACK; less only in tests)
-	uint32_t leafStep;                    // triangles of a leaf a lane scans per round (the rest waits for the next round)
 	uint32_t npix, tilesX, nChunks0, spillStride;
 	uint32_t cap;                         // entries per ray list / hit list (npix + room for reservation holes)
 };
@@ -606,108 +602,6 @@ DEVI void alpha_tri( const DevScene &S, const TriRay &R, const Rec &rc, const Tr
 }
 
 // ---------------------------------------------------------------------------
-// Leaf scans of a sparse wave.  Towards the end of a chunk, and for whole
-// passes in the deep slots, a wave carries a handful of long rays: one lane
-// walks through its leaf triangle by triangle while sixty others idle.  When
-// at most RT_COOP_LANES lanes have a leaf to scan, the wave scans those leaves
-// one after the other with ALL lanes instead, lane i testing triangle i
-// against the owner's ray (broadcast through scalar registers).  The values
-// are the ones the owner would have computed; the owner's sequential rule
-// (strictly smaller distance wins, so the lowest index among equals) is the
-// minimum over the lanes with the lowest lane index among equals, and the
-// shadow sum is accumulated in ascending triangle order.
-// ---------------------------------------------------------------------------
-#ifndef RT_COOP_LANES
-#define RT_COOP_LANES 3
-#endif
-DEVI float lane_f( float x, uint32_t lane ) { return __uint_as_float( (uint32_t) __builtin_amdgcn_readlane( (int) __float_as_uint( x ), (int) lane ) ); }
-DEVI uint32_t lane_u( uint32_t x, uint32_t lane ) { return (uint32_t) __builtin_amdgcn_readlane( (int) x, (int) lane ); }
-DEVI float wave_min( float x )
-{
-	for ( int o = 32; o > 0; o >>= 1 )
-	{
-		const float y = __shfl_xor( x, o );
-		x = y < x ? y : x;
-	}
-	return x;
-}
-DEVI TriRay lane_tri_ray( const Ray &r, uint32_t lane )
-{
-	return tri_ray( F3( lane_f( r.src.x, lane ), lane_f( r.src.y, lane ), lane_f( r.src.z, lane ) ),
-		F3( lane_f( r.dest.x, lane ), lane_f( r.dest.y, lane ), lane_f( r.dest.z, lane ) ) );
-}
-
-// closest-hit leaf scan of lane `owner` by the whole wave
-template <bool STATS>
-DEVI void nearest_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, uint32_t owner, float &lt, NearHit &h, Tally &tl )
-{
-	const uint32_t first = lane_u( t.n.x, owner ), cnt = lane_u( t.n.y, owner ) >> 2;
-	const TriRay R = lane_tri_ray( r, owner );
-	float best = INFINITY, bu = 0.0f, bv = 0.0f;
-	uint32_t bid = 0u;
-	bool found = false;
-	for ( uint32_t base = 0; base < cnt; base += 64u )
-	{
-		const uint32_t i = base + lane_id();
-		const bool ok = i < cnt;
-		const Rec rc = load_rec( S.recs, first + ( ok ? i : 0u ) );
-		float tt, u, v;
-		const bool hit = ray_tri( R, rc, tt, u, v ) && ok;
-		const float m = wave_min( hit ? tt : INFINITY );
-		if ( m < best )
-		{
-			const uint32_t win = (uint32_t) __ffsll( (long long) __ballot( hit && tt == m ) ) - 1u;
-			best = m;
-			bu = lane_f( u, win );
-			bv = lane_f( v, win );
-			bid = lane_u( rec_tri( rc ), win );
-			found = true;
-		}
-	}
-	if ( lane_id() == owner )
-	{
-		// lt: what an earlier round found in the first part of this leaf (strictly smaller wins)
-		if ( found && best < lt )
-		{
-			lt = best;
-			h.minU = bu;
-			h.minV = bv;
-			h.prN = bid;
-			h.nearestB = 1;
-		}
-		if ( STATS ) { tl.tris += cnt; tl.triSlots += 64.0f * (float) ( ( cnt + 63u ) / 64u ); }
-	}
-}
-
-// shadow leaf scan of lane `owner` by the whole wave
-template <bool STATS>
-DEVI void alpha_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, float d, uint32_t owner, float &alpha, Tally &tl )
-{
-	const uint32_t first = lane_u( t.n.x, owner ), cnt = lane_u( t.n.y, owner ) >> 2;
-	const TriRay R = lane_tri_ray( r, owner );
-	const float dO = lane_f( d, owner ), tN = lane_f( t.tNear, owner ), tF = lane_f( t.tFar, owner );
-	float sum = lane_f( alpha, owner );
-	for ( uint32_t base = 0; base < cnt; base += 64u )
-	{
-		const uint32_t i = base + lane_id();
-		const bool ok = i < cnt;
-		const Rec rc = load_rec( S.recs, first + ( ok ? i : 0u ) );
-		float tt, u, v;
-		const bool hit = ray_tri( R, rc, tt, u, v ) && ok && ( tt < dO ) && ( tt < tF ) && ( tt > tN );
-		float a = 0.0f;
-		if ( hit )
-			a = S.mats[rec_mat( rc )].color.a;
-		for ( unsigned long long w = __ballot( hit ); w; w &= w - 1ull )
-			sum += lane_f( a, (uint32_t) __ffsll( (long long) w ) - 1u );
-	}
-	if ( lane_id() == owner )
-	{
-		alpha = sum;
-		if ( STATS ) { tl.tris += cnt; tl.triSlots += 64.0f * (float) ( ( cnt + 63u ) / 64u ); }
-	}
-}
-
-// ---------------------------------------------------------------------------
 // Cooperative walk: the rays a wave has left share its 64 lanes
 //
 // Rays are of very different length (a ray that skims the surface passes
@@ -762,7 +656,7 @@ DEVI void alpha_leaf_coop( const DevScene &S, const Ray &r, const Trav &t, float
 #endif
 
 #ifdef RT_PROFILE_CHUNKS
-struct Prof { uint32_t lock, coop, iters; unsigned long long tExpand, tScan, tCoop; };
+struct Prof { uint32_t lock, coop, iters; unsigned long long tExpand, tScan, tCoop, tDescend, tLeaf; };
 #define PROF_T0( v ) const unsigned long long v = wall_clock64()
 #define PROF_ADD( f, v ) ( pf.f += wall_clock64() - v )
 #define PROF_ARG , Prof &pf
@@ -1232,19 +1126,17 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 // keep their own lane, and the gear change waits for them.
 template <bool STATS>
 DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, NearHit &h, Tally &tl,
-	uint32_t coopLive, uint32_t coopCap, bool atOnce, uint32_t step PROF_ARG )
+	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	// the cooperative walk is the last thing a chunk does (nothing of the lane-per-ray
 	// walk stays live across it): rays parallel to an axis are finished first
 	const bool ownLane = coopLive == 0u || axis_parallel( r );
 	bool walked = atOnce;
-	float lt = INFINITY;
 	while ( __ballot( live ) != 0ull )
 	{
 		if ( walked && (uint32_t) __popcll( __ballot( live ) ) <= coopLive && __ballot( live && ownLane ) == 0ull )
 		{
-			// (a lane that is part-way through a leaf starts that leaf again: same minimum)
 			PROF_T0( pc );
 			nearest_coop<STATS>( S, r, live, t, h, tl, coopCap PROF_PASS );
 			PROF_ADD( tCoop, pc );
@@ -1252,27 +1144,21 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 		}
 		walked = true;
 		PROF_INC( lock );
-		// A lane scans at most `step` triangles of its leaf per round and keeps the rest
-		// (t.n = first record / count still to scan, lt = the minimum so far) for the
-		// next one: a long leaf does not hold up the lanes that are through theirs.
+		float lt = INFINITY;
 		uint32_t cnt = 0u;
+		PROF_T0( pd );
 		if ( live )
 		{
 			trav_descend<STATS>( S, src, inv, dest, st, t, tl );
 			cnt = t.n.y >> 2;
 		}
-		unsigned long long m = __ballot( live && cnt != 0u );
-		if ( m != 0ull && (uint32_t) __popcll( m ) <= RT_COOP_LANES )
-		{
-			for ( ; m; m &= m - 1ull )
-				nearest_leaf_coop<STATS>( S, r, t, (uint32_t) __ffsll( (long long) m ) - 1u, lt, h, tl );
-		}
-		else if ( live && cnt != 0u )
+		PROF_ADD( tDescend, pd );
+		PROF_T0( pl );
+		if ( live && cnt != 0u )
 		{
 			// Two records are kept in flight and take turns (no register copies); the
 			// array ends with one spare record, so the look-ahead load of the last
 			// triangle stays inside the buffer.
-			if ( cnt > step ) cnt = step;
 			uint32_t i = t.n.x;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
@@ -1286,21 +1172,14 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 				if ( ++i == end ) break;
 			}
 		}
+		PROF_ADD( tLeaf, pl );
 		if ( live )
 		{
-			t.n.x += cnt;
-			t.n.y -= cnt << 2;
-			if ( ( t.n.y >> 2 ) == 0u )
-			{
-				h.minT = lt;
-				if ( h.nearestB && ( h.minT < t.tFar ) )
-					live = false;
-				else
-				{
-					live = trav_pop<STATS>( S, st, t, tl );
-					lt = INFINITY;
-				}
-			}
+			h.minT = lt;
+			if ( h.nearestB && ( h.minT < t.tFar ) )
+				live = false;
+			else
+				live = trav_pop<STATS>( S, st, t, tl );
 		}
 	}
 }
@@ -1308,7 +1187,7 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 // shadow query of every lane with `live` set, CL/rt_funcs_primitives.cl:295-378
 template <bool STATS>
 DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const StackRef &st, bool live, Trav &t, float d, float &alpha, Tally &tl,
-	uint32_t coopLive, uint32_t coopCap, bool atOnce, uint32_t step PROF_ARG )
+	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	const bool ownLane = coopLive == 0u || axis_parallel( r );
@@ -1328,16 +1207,8 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 			trav_descend<STATS>( S, src, inv, dest, st, t, tl );
 			cnt = t.n.y >> 2;
 		}
-		unsigned long long m = __ballot( live && cnt != 0u );
-		if ( m != 0ull && (uint32_t) __popcll( m ) <= RT_COOP_LANES )
+		if ( live && cnt != 0u )
 		{
-			for ( ; m; m &= m - 1ull )
-				alpha_leaf_coop<STATS>( S, r, t, d, (uint32_t) __ffsll( (long long) m ) - 1u, alpha, tl );
-		}
-		else if ( live && cnt != 0u )
-		{
-			// at most `step` triangles per round, the rest of the leaf in the next one (see nearest_wave)
-			if ( cnt > step ) cnt = step;
 			uint32_t i = t.n.x;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
@@ -1353,13 +1224,11 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 		}
 		if ( live )
 		{
-			t.n.x += cnt;
-			t.n.y -= cnt << 2;
 			// the caller clamps the sum to [0,1]: with non-negative opacities it
 			// cannot drop below 1 again, the rest of the ray is irrelevant
 			if ( S.alphaMonotone && alpha >= 1.0f )
 				live = false;
-			else if ( ( t.n.y >> 2 ) == 0u )
+			else
 				live = trav_pop<STATS>( S, st, t, tl );
 		}
 	}
@@ -1757,6 +1626,9 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 	out.block = resv_block( count );
 	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_DYN, shift ) )
 	{
+#ifdef RT_PROFILE_CHUNKS
+		const unsigned long long cs = wall_clock64();
+#endif
 		const uint32_t e = first + lane_id();
 		RayHead rh;
 		rh.pix = rh.pk = 0u;
@@ -1777,14 +1649,21 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 			live = trav_begin<STATS>( S, rh.ray, t, tl );
 		}
 #ifdef RT_PROFILE_CHUNKS
-		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull };
+		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, 0ull };
 		const unsigned long long c0 = wall_clock64();
 #endif
-		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ), W.leafStep PROF_PASS );
+		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
+#ifdef RT_PROFILE_CHUNKS
+		const unsigned long long c1 = wall_clock64();
+#endif
 		finish_closest( S, W, slot, wantIds, out, valid, e, rh, h, sph );
 #ifdef RT_PROFILE_CHUNKS
 		if ( lane_id() == 0u )
 		{
+			atomicAdd( &W.ctr->tFinish[slot], wall_clock64() - c1 );
+			atomicAdd( &W.ctr->tSetup[slot], c0 - cs );
+			atomicAdd( &W.ctr->tDescend[slot], pf.tDescend );
+			atomicAdd( &W.ctr->tLeaf[slot], pf.tLeaf );
 			const unsigned long long dt = ( wall_clock64() - c0 ) / 1000ull;       // 100 MHz ticks -> 10 us
 			atomicAdd( &W.ctr->chunkHist[slot][dt < 63ull ? dt : 63ull], 1u );
 			atomicAdd( &W.ctr->lockRounds[slot], (unsigned long long) pf.lock );
@@ -1888,9 +1767,9 @@ __global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScen
 			}
 		}
 #ifdef RT_PROFILE_CHUNKS
-		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull };
+		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, 0ull };
 #endif
-		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ), W.leafStep PROF_PASS );
+		alpha_wave<STATS>( S, sh, tri_ray( sh.src, sh.dest ), st, live, t, d, a, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
 		if ( item )
 			W.shadow[( (size_t) slot * S.nLights + o ) * W.cap + hh] = shadowed + clampf( a, 0.0f, 1.0f );
 	}
@@ -2099,7 +1978,6 @@ struct rt_hip_ctx
 	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
 	int gridShadow[2] = { 0, 0 }, gridLight = 0;
 	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK, coopFill = 8, coopAtOnce = 0;
-	int leafStep = RT_LEAF_STEP, leafStepShadow = RT_LEAF_STEP;
 	uint32_t bigFrame = RT_BIG_FRAME;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[RT_AUX_STREAMS] = {};        // shadow + lighting passes (slot k on stream k mod RT_AUX_STREAMS)
@@ -2217,8 +2095,6 @@ rt_hip_ctx *rt_hip_create( int device )
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
 	}
 	// development knob
-	if ( const char *v = getenv( "RT_LEAF_STEP" ) ) c->leafStep = c->leafStepShadow = atoi( v ) > 0 ? atoi( v ) : RT_LEAF_STEP;
-	if ( const char *v = getenv( "RT_LEAF_STEP_SHADOW" ) ) c->leafStepShadow = atoi( v ) > 0 ? atoi( v ) : RT_LEAF_STEP;
 	if ( const char *v = getenv( "RT_COOP_LIVE" ) ) c->coopLive = atoi( v );
 	if ( c->coopLive < 0 || c->coopLive > 32 ) c->coopLive = 0;
 	if ( const char *v = getenv( "RT_COOP_FILL" ) ) c->coopFill = atoi( v ) > 0 && atoi( v ) < 256 ? atoi( v ) : 8;
@@ -2677,7 +2553,6 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		if ( overlap ) Wx.spill = W.spill + (size_t) ( 1 + k % RT_AUX_STREAMS ) * W.spillStride * RT_SPILL_CAP;
 		Wx.coopLive = c->coopShadow && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wx.coopCap = (uint32_t) c->coopCap;
-		Wx.leafStep = (uint32_t) c->leafStepShadow;
 
 		// a persistent grid never needs more waves than there are chunks
 		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
@@ -2701,7 +2576,6 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		Work Wc = W;
 		Wc.coopLive = c->coopClosest && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wc.coopCap = (uint32_t) c->coopCap;
-		Wc.leafStep = (uint32_t) c->leafStep;
 		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, Wc, k, ids ? 1 : 0 );
 		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
 		if ( overlap )
@@ -2935,6 +2809,7 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 			(double) h.coopIters[k] / ( h.chunksSeen[k] ? h.chunksSeen[k] : 1 ), h.maxIters[k] );
 		const double n = h.chunksSeen[k] ? (double) h.chunksSeen[k] : 1.0;
 		fprintf( stderr, " [us per chunk: total %.1f, cooperative %.1f of which expand %.1f scan %.1f]", h.tChunk[k] / n / 100.0, h.tCoop[k] / n / 100.0, h.tExpand[k] / n / 100.0, h.tScan[k] / n / 100.0 );
+		fprintf( stderr, " [lane-per-ray: descend %.1f leaf %.1f; finish %.1f setup %.1f]", h.tDescend[k] / n / 100.0, h.tLeaf[k] / n / 100.0, h.tFinish[k] / n / 100.0, h.tSetup[k] / n / 100.0 );
 		if ( getenv( "RT_PROF_HIST" ) ) for ( int b = 0; b < 64; ++b ) if ( h.chunkHist[k][b] ) fprintf( stderr, " %d:%u", b, h.chunkHist[k][b] );
 		fprintf( stderr, "\n" );
 	}
