@@ -150,9 +150,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
-                         "buffers, one shared scene), so a frame's sparse last passes overlap the next frame's first ones")
+                         "buffers, one shared scene), so a frame's sparse last passes overlap the next frame's first ones.  "
+                         "0 = by the size of a rank's share: 2 for half a frame or more (a third one gains nothing: 6.85 "
+                         "against 6.79 ms), 3 for a quarter or less (1/8 frame: 1.31 against 1.39 ms)")
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -198,7 +200,12 @@ def main():
 
     split = world > 1 and not sequence
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world) if split else sc.h
-    n_slots = max(1, min(args.in_flight, 4))
+    def slots_for(parts):
+        return max(1, min(args.in_flight, 4)) if args.in_flight else (2 if parts <= 2 or sequence else 3)
+
+    n_slots = slots_for(world if split else 1)
+    # (the strong-scaling proxy of a single-rank run renders quarter and eighth shares: one more context for those)
+    n_built = max(n_slots, slots_for(8)) if world == 1 and not sequence and not args.no_proxy and not args.timed_only else n_slots
 
     # ---- one context per frame in flight: own stream, own work buffers, own output and exchange; the scene is
     # resident once and shared
@@ -206,7 +213,7 @@ def main():
         pass
 
     slots = []
-    for k in range(n_slots):
+    for k in range(n_built):
         sl = Slot()
         sl.stream = torch.cuda.Stream()          # (not the default stream: work on it would wait for, and hold up, the other frame)
         sl.r = HipRenderer(local_dev, stream=sl.stream.cuda_stream)
@@ -268,6 +275,7 @@ def main():
         else:
             gather_kind = f"torch.distributed.gather over {backend} (rehearsal: ranks share a GPU, which RCCL refuses)"
     use_comm = split and all(sl.comm for sl in slots)
+    all_slots, slots = slots, slots[:n_slots]
 
     trace = bool(os.environ.get("RT_BENCH_TRACE"))     # debugging aid: synchronise and report after every frame
 
@@ -403,19 +411,21 @@ def main():
     if world == 1 and not sequence and not args.no_proxy and not args.timed_only:
         proxy = {}
         for parts in (2, 4, 8):
+            use = all_slots[:slots_for(parts)]
             outs = []
-            for sl in slots:
+            for sl in use:
                 sl.r.set_tile(rdist.BAND_H, parts, 0)
                 outs.append(torch.zeros((rdist.padded_rows(sc.h, rdist.BAND_H, parts), sc.w, 4), dtype=torch.uint8, device=dev))
-            for i in range(2 * n_slots):
-                slots[i % n_slots].r.render(0, d_out=outs[i % n_slots].data_ptr())
+            for i in range(2 * len(use)):
+                use[i % len(use)].r.render(0, d_out=outs[i % len(use)].data_ptr())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(12):
-                slots[i % n_slots].r.render(0, d_out=outs[i % n_slots].data_ptr())
+                use[i % len(use)].r.render(0, d_out=outs[i % len(use)].data_ptr())
             torch.cuda.synchronize()
             proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 12 * 1e3, 4)
-        for sl in slots:
+            proxy[f"part_0_of_{parts}_frames_in_flight"] = len(use)
+        for sl in all_slots:
             sl.r.set_tile(rdist.BAND_H, 1, 0)
 
     if rank == 0:
@@ -424,7 +434,7 @@ def main():
         if proxy is not None:
             proxy["full_frame_ms"] = round(ms_per_step, 4)
             proxy["note"] = ("step time of rank 0's share of an N-way band split of this frame on ONE GPU, scheduled as the timed "
-                             "region schedules the full frame (same frames in flight), render only (no exchange): "
+                             "region of an N-rank run schedules it (frames in flight as given), render only (no exchange): "
                              "full_frame_ms / part_0_of_N_ms bounds the N-GPU speed-up from above")
         counters = committed_counters(args, dominant, world)
         out = {
@@ -484,10 +494,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    for sl in slots:
+    for sl in all_slots:
         if sl.comm:
             sl.comm.close()
-    for sl in reversed(slots):
+    for sl in reversed(all_slots):               # (the first one owns the scene the others read)
         sl.r.close()
     if world > 1:
         dist.barrier()
