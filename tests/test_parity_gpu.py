@@ -969,3 +969,44 @@ def test_frames_in_flight_on_contexts_that_share_one_scene():
         finally:
             a.close()
             b.close()
+
+
+def test_launch_intervals_of_two_contexts_share_one_clock():
+    """rt_hip_kernel_intervals: every launch of the timed frames of a context, on the clock of another context's
+    first timed frame.  Intervals are well-formed, a frame's launches lie inside the frame's own interval, and the
+    second context's frames start after the first context's first frame did."""
+    import torch
+    from raytracing_amd.pipe import RT_HIP_TIMING
+    sc = scenes.sphere_scene(100, 80, 256, 160, reflect=0.5)
+    v, t = sc.flatten()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    a = HipRenderer(0, stream=streams[0].cuda_stream)
+    a.load_scene(sc, FlatTree.build(v, t, 18, 7))
+    b = HipRenderer(0, stream=streams[1].cuda_stream)
+    b.share_scene(a, sc)
+    with pytest.raises(Exception, match="RT_HIP_TIMING"):
+        a.kernel_intervals()
+    n_frames = 3
+    for _ in range(n_frames):
+        a.render(RT_HIP_TIMING)
+        b.render(RT_HIP_TIMING)
+    ia, ib = a.kernel_intervals(), b.kernel_intervals(origin=a)
+    slots = sc.stack_size
+    for iv in (ia, ib):
+        assert len(iv) == n_frames * (3 * slots + 2)
+        assert all(e >= s for _, s, e in iv)
+        frames = [x for x in iv if x[0] == "frame"]
+        assert len(frames) == n_frames and frames == sorted(frames, key=lambda x: x[1])
+        per = 3 * slots + 2
+        for f in range(n_frames):
+            chunk = iv[f * per:(f + 1) * per]
+            fr = [x for x in chunk if x[0] == "frame"][0]
+            assert all(fr[1] - 1e-3 <= s and e <= fr[2] + 1e-3 for k, s, e in chunk if k != "frame")
+            assert sorted(k for k, _, _ in chunk) == sorted(["closest", "shadow", "shade"] * slots + ["fold", "frame"])
+    assert min(s for _, s, _ in ia) >= -1e-3 and min(s for _, s, _ in ib) >= -1e-3
+    ms, launches, wall = a.kernel_times_wall()          # the read-out that resets the timings
+    assert launches["closest"] == slots and wall["closest"] <= ms["closest"] * 1.001
+    with pytest.raises(Exception, match="RT_HIP_TIMING"):
+        a.kernel_intervals()
+    b.close()
+    a.close()

@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(n, port):
+def run_bench(n, port, extra=()):
     # RT_BENCH_WATCHDOG only arms a stack dump + exit should a rank stop making progress; the frames
     # run exactly as in a normal bench run: overlapped schedule (closest-hit chain + two auxiliary
     # streams per rank), no synchronisation between frames
     env = dict(os.environ, RT_DIST_BACKEND="gloo", RT_BENCH_WATCHDOG="150", PYTHONPATH=ROOT)
-    args = ["--gpus", str(n), "--steps", "6", "--warmup", "2", "--workload", "config2", "--depth", "20", "--no-cpu-baseline"]
+    args = ["--gpus", str(n), "--steps", "6", "--warmup", "2", "--workload", "config2", "--depth", "20", "--no-cpu-baseline"] + list(extra)
     if n == 1:
         cmd = [sys.executable, "bench.py"] + args
     else:
@@ -41,3 +41,25 @@ def test_two_ranks_on_one_gpu_trace_the_same_frame():
     assert two["cpu_baseline"] is None and two["roofline"]["traffic"] is None
     assert "bands of 16 rows over 2 GPUs" in two["config"]["parallelism"]
     assert two["value"] > 0 and two["ms_per_step"] > 0
+
+
+def test_single_rank_line_has_what_the_contract_asks_for():
+    """The single-rank line: roofline with the wall-attributed time basis (never more than the step time), the
+    strong-scaling proxy with the frames in flight it used, and the profiler variant of the run."""
+    b = run_bench(1, 0)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["vs_baseline"] is None and b["dtype"] == "f32" and b["config"]["frames_in_flight"] == 2
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    wall = b["kernel_wall_ms_per_frame_rank0"]
+    assert all(0 < wall[k] <= b["ms_per_step"] * 1.02 for k in ("closest", "shadow", "shade"))
+    assert wall["closest"] <= b["kernel_ms_per_frame_rank0"]["closest"] * 1.001
+    p = b["strong_scaling_proxy"]
+    assert p["part_0_of_8_frames_in_flight"] == 3 and p["part_0_of_2_frames_in_flight"] == 2
+    assert 0 < p["part_0_of_8_ms"] < p["part_0_of_2_ms"] < 1.2 * b["ms_per_step"]
+    t = run_bench(1, 0, ["--timed-only"])
+    assert t["strong_scaling_proxy"] is None if "strong_scaling_proxy" in t else True
+    assert t["kernel_ms_per_frame_isolated_rank0"] is None and t["config"]["frame_latency_ms_alone"] is None
+    assert t["config"]["rays_per_step"] == b["config"]["rays_per_step"]
