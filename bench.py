@@ -116,7 +116,8 @@ def cpu_baseline(sc, v, t, tree, seconds):
             if dt >= 0.5 * budget or step == 1:
                 break
             step = int(max(1, min(step - 1, step * (dt / budget) ** 0.5)))     # denser lattice, about `budget` seconds
-        what = "the whole frame" if step == 1 else f"every {step}th pixel of every {step}th row of the same frame"
+        nth = {2: "second", 3: "third"}.get(step, f"{step}th")
+        what = "the whole frame" if step == 1 else f"every {nth} pixel of every {nth} row of the same frame"
         return rays / dt / 1e6, f"{what} ({rays} rays in {dt:.1f} s on {threads} threads)"
 
     nodes, idx = tree.expand()
@@ -481,7 +482,8 @@ def main():
                          "frac_of_l2_roof": round(achieved / L2_PEAK_GBS, 5), "l2_peak": L2_PEAK_GBS,
                          "frac_of_infinity_cache_roof": round(achieved / MALL_PEAK_GBS, 5), "infinity_cache_peak": MALL_PEAK_GBS,
                          "frame_algorithmic_bytes": int(frame_bytes),
-                         "frame_achieved_GBs": round(gbs(frame_bytes, kms["frame"]), 2),
+                         # all kernels of a frame: algorithmic bytes of this rank's frame / the step time
+                         "frame_achieved_GBs": round(gbs(frame_bytes, ms_per_step), 2),
                          "per_ray": {"nodes": round(sst["nodeVisits"] / all_rays, 2), "tri_tests": round(sst["triTests"] / all_rays, 2)},
                          "traversal_stack": {"deepest": int(sst["maxStack"]), "pushes_beyond_lds": int(sst["spillPushes"]),
                                              "rays": int(all_rays)},
