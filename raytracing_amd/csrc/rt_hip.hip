@@ -98,7 +98,7 @@
 #define RT_COOP_LIVE 32
 #endif
 #ifndef RT_COOP_MIN_SHIFT
-#define RT_COOP_MIN_SHIFT 2u
+#define RT_COOP_MIN_SHIFT 3u
 #endif
 #ifndef RT_STREAM_OCC
 #define RT_STREAM_OCC 4      // blocks per CU of the streaming (non-traversal) passes
@@ -1977,7 +1977,7 @@ struct rt_hip_ctx
 	bool workDirty = true;
 	int gridClosest[2][2] = { { 0, 0 }, { 0, 0 } };   // [big frame][stats]
 	int gridShadow[2] = { 0, 0 }, gridLight = 0;
-	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK, coopFill = 8, coopAtOnce = 0;
+	int coopLive = RT_COOP_LIVE, coopShadow = 1, coopClosest = 1, coopCap = RT_LDS_STACK, coopFill = 4, coopAtOnce = 0;
 	uint32_t bigFrame = RT_BIG_FRAME;
 	int occShadow[2] = { 1, 1 };
 	hipStream_t aux[RT_AUX_STREAMS] = {};        // shadow + lighting passes (slot k on stream k mod RT_AUX_STREAMS)
@@ -2097,7 +2097,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	// development knob
 	if ( const char *v = getenv( "RT_COOP_LIVE" ) ) c->coopLive = atoi( v );
 	if ( c->coopLive < 0 || c->coopLive > 32 ) c->coopLive = 0;
-	if ( const char *v = getenv( "RT_COOP_FILL" ) ) c->coopFill = atoi( v ) > 0 && atoi( v ) < 256 ? atoi( v ) : 8;
+	if ( const char *v = getenv( "RT_COOP_FILL" ) ) c->coopFill = atoi( v ) > 0 && atoi( v ) < 256 ? atoi( v ) : 4;
 	if ( const char *v = getenv( "RT_COOP_ATONCE" ) ) c->coopAtOnce = atoi( v );
 	if ( const char *v = getenv( "RT_COOP_SHADOW" ) ) c->coopShadow = atoi( v );
 	if ( const char *v = getenv( "RT_COOP_CLOSEST" ) ) c->coopClosest = atoi( v );
