@@ -1010,3 +1010,68 @@ def test_launch_intervals_of_two_contexts_share_one_clock():
         a.kernel_intervals()
     b.close()
     a.close()
+
+
+def test_c_program_on_the_hip_layer_renders_the_frame_the_python_mirror_renders():
+    """apps/abi_example.c: the HIP layer called from plain C (host tree build, uploads, a second context on the first
+    one's resident scene, two frames in flight, read-back).  It checks by itself that both contexts agree; here its
+    frame hash is compared with the same scene rendered through the ctypes mirror."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "apps", "abi_example")
+    if not os.path.exists(exe):
+        pytest.fail("apps/abi_example is missing: run `make -C raytracing_amd/csrc app` (build() does)")
+    w, h, n = 200, 120, 24
+    out = subprocess.run([exe, str(w), str(h)], check=True, capture_output=True, text=True, timeout=120).stdout.split()
+    assert out[0] == f"{w}x{h}" and int(out[2]) == 2 * n * n
+    f32 = np.float32
+    i = np.arange(n + 1, dtype=np.float32)
+    x = f32(-60.0) + f32(120.0) * i / f32(n)
+    z = f32(40.0) + f32(120.0) * i / f32(n)
+    X, Z = np.meshgrid(x, z)                              # row j = z index, column i = x index
+    dx, dz = X / f32(30.0), (Z - f32(100.0)) / f32(30.0)
+    Y = f32(25.0) - f32(12.0) / (f32(1.0) + dx * dx + dz * dz)
+    assert Y.dtype == np.float32
+    v = np.zeros((n + 1) * (n + 1), T.vertex)
+    v["pos"]["x"], v["pos"]["y"], v["pos"]["z"] = X.ravel(), Y.ravel(), Z.ravel()
+    v["norm"]["y"] = -1.0
+    t = np.zeros(2 * n * n, T.triangle)
+    o = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).ravel()
+    t["pV0"][0::2], t["pV1"][0::2], t["pV2"][0::2] = o, o + 1, o + n + 1
+    t["pV0"][1::2], t["pV1"][1::2], t["pV2"][1::2] = o + 1, o + n + 2, o + n + 1
+    sc = scenes.Scene("abi_example", w, h, scenes.make_camera(w, h))
+    rest = ((0.0, 0.05, 0.05, 0.05), (0.0, 0.6, 0.6, 0.6), (20.0, 0.3, 0.3, 0.3), (0.0, 0.4, 0.4, 0.4), 0.0, 1.0)
+    sc.materials[0] = T.make_material((1.0, 0.8, 0.7, 0.5), *rest)
+    sc.materials[1] = T.make_material((1.0, 0.2, 0.4, 0.9), *rest)
+    sc.spheres.append(scenes.make_sphere((10.0, 0.0, 90.0), 9.0, 1))
+    sc.lights.append(scenes.make_light((-20.0, -35.0, 0.0), 100.0))
+    sc.meshes.append(scenes.Mesh(v, t, 0))
+    sc.stack_size = 4
+    img, _, _, tree = hip_render(sc, 12, 4, flags=RT_HIP_HITIDS)
+    tree.release()
+    hsh = 1469598103934665603
+    for byte in img.tobytes():
+        hsh = ((hsh ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(out[6]) == int(np.count_nonzero(img[..., :3].any(axis=-1)))
+    assert out[8] == f"{hsh:016x}"
+
+
+def test_fly_through_frames_are_dealt_round_robin_to_the_ranks(tmp_path):
+    """Frame f belongs to rank f mod N and no rank needs the others: two ranks started one after the other (as
+    two GPUs would run side by side) together write every frame of the sequence exactly once."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 5
+    counts = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+        out = subprocess.run([sys.executable, os.path.join(root, "apps", "flythrough.py"), "--frames", str(n), "--size", "96x64",
+                              "--lon", "30", "--lat", "16", "--depth", "12", "--leaf", "7", "--out", str(tmp_path / f"r{rank}")],
+                             check=True, capture_output=True, text=True, timeout=300, env=env).stdout
+        rec = json.loads(out.strip().splitlines()[-1])
+        assert (rec["rank"], rec["world"]) == (rank, 2)
+        counts.append(rec["frames"])
+        assert sorted(os.listdir(tmp_path / f"r{rank}")) == sorted(f"{f + 8}.png" for f in range(rank, n, 2))
+    assert counts == [3, 2]
