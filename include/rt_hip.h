@@ -190,7 +190,9 @@ int  rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out );     /* synchronous */
 /* Per-frame kernel time in ms, averaged over the frames rendered with
  * RT_HIP_TIMING since the previous call (at most the last 32): ms[0] =
  * closest-hit passes, ms[1] = shadow passes, ms[2] = lighting passes, ms[3] = fold + store, ms[4] = whole frame; launches[i] = launches
- * per frame.  Measured with HIP events on the stream each kernel runs on.
+ * per frame.  Measured with HIP events on the stream each kernel runs on: one behind every kernel; a kernel's
+ * start is the end of the last of its predecessors (the kernel before it on its stream, the kernel its stream
+ * waited for), so a timed frame carries few markers more than an untimed one.
  * With RT_PARAM_OVERLAP = 1 passes share the chip, so ms[0..3] add up to more
  * than ms[4]; set it to 0 to time every pass running alone. */
 int  rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] );

@@ -1986,8 +1986,10 @@ struct rt_hip_ctx
 	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
 	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
-	// [frame][(slot * 3 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop
+	// [frame][(slot * 3 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop; of the
+	// start events only that of the first kernel is recorded (enqueue_frame, frame_times)
 	hipEvent_t ev[RT_TIMED_FRAMES][6 * RT_MAX_SLOTS + 4] = {};
+	bool evOverlap[RT_TIMED_FRAMES] = {};   // schedule of each of them (decides which kernel waited for which)
 	bool haveEvents = false;
 	int timedSlots = 0, timedFrames = 0;
 	uint32_t validPixels = 0;
@@ -2536,14 +2538,24 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		c->timedFrames = 0;
 	}
 	hipEvent_t *ev = c->ev[c->timedFrames % RT_TIMED_FRAMES];
-	hipEvent_t *evFold = ev + 6 * RT_MAX_SLOTS, *evFrame = evFold + 2;
+	hipEvent_t *evFrame = ev + 6 * RT_MAX_SLOTS + 2;
 	const bool big = W.npix >= c->bigFrame;
 	const int lights = S.nLights > 0 ? S.nLights : 1;
 
+	// Timing records one event behind every kernel and none in front of it: a kernel starts when the
+	// last of its predecessors has ended (the kernel before it on its stream, and the event its stream
+	// waited for), which the read-out works out from the end events.  In the overlapped schedule the
+	// end events of k_closest<k> and k_light<k> are the very events the fork and the join need, so a
+	// timed frame puts 8 markers more into the streams than an untimed one, not 34.
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
 	HIPCHK( hipMemsetAsync( W.ctr, 0, sizeof( Counters ), s ) );
 	if ( W.npix == 0 )
 		return 0;
+	if ( timing )
+	{
+		c->evOverlap[c->timedFrames % RT_TIMED_FRAMES] = overlap;
+		HIPCHK( hipEventRecord( ev[0], s ) );          // start of k_closest<0> (behind the memset)
+	}
 	for ( int k = 0; k < S.stackSize; ++k )
 	{
 		hipEvent_t *e = ev + 6 * k;
@@ -2569,7 +2581,6 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 			if ( gl > gridCap ) gl = gridCap;
 		}
 
-		if ( timing ) HIPCHK( hipEventRecord( e[0], s ) );
 		void ( *closest )( DevScene, Work, int, int ) = big
 			? ( stats ? k_closest<true, RT_WAVES_CLOSEST_STATS> : k_closest<false, RT_WAVES_CLOSEST_BIG> )
 			: ( stats ? k_closest<true, RT_WAVES_CLOSEST_STATS> : k_closest<false, RT_WAVES_CLOSEST> );
@@ -2577,30 +2588,22 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		Wc.coopLive = c->coopClosest && c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
 		Wc.coopCap = (uint32_t) c->coopCap;
 		hipLaunchKernelGGL( closest, dim3( gc ), dim3( RT_BLOCK ), 0, s, S, Wc, k, ids ? 1 : 0 );
-		if ( timing ) HIPCHK( hipEventRecord( e[1], s ) );
-		if ( overlap )
-		{
-			HIPCHK( hipEventRecord( c->evHit[k], s ) );
-			HIPCHK( hipStreamWaitEvent( x, c->evHit[k], 0 ) );
-		}
+		hipEvent_t hit = timing ? e[1] : c->evHit[k];
+		if ( timing || overlap ) HIPCHK( hipEventRecord( hit, s ) );
+		if ( overlap ) HIPCHK( hipStreamWaitEvent( x, hit, 0 ) );
 
-		if ( timing ) HIPCHK( hipEventRecord( e[2], x ) );
 		if ( stats ) hipLaunchKernelGGL( k_shadow<true>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wx, k );
 		else hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wx, k );
 		if ( timing ) HIPCHK( hipEventRecord( e[3], x ) );
 
-
-		if ( timing ) HIPCHK( hipEventRecord( e[4], x ) );
 		hipLaunchKernelGGL( k_light, dim3( gl ), dim3( RT_BLOCK ), 0, x, S, W, k );
-		if ( timing ) HIPCHK( hipEventRecord( e[5], x ) );
-		if ( overlap ) HIPCHK( hipEventRecord( c->evLit[k], x ) );
+		hipEvent_t lit = timing ? e[5] : c->evLit[k];
+		if ( timing || overlap ) HIPCHK( hipEventRecord( lit, x ) );
 	}
 	if ( overlap )
 		for ( int k = 0; k < S.stackSize; ++k )
-			HIPCHK( hipStreamWaitEvent( s, c->evLit[k], 0 ) );
-	if ( timing ) HIPCHK( hipEventRecord( evFold[0], s ) );
+			HIPCHK( hipStreamWaitEvent( s, timing ? ev[6 * k + 5] : c->evLit[k], 0 ) );
 	hipLaunchKernelGGL( k_fold, dim3( ( W.npix + RT_BLOCK - 1 ) / RT_BLOCK ), dim3( RT_BLOCK ), 0, s, W, out, S.stackSize );
-	if ( timing ) HIPCHK( hipEventRecord( evFold[1], s ) );
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[1], s ) );
 	if ( timing ) ++c->timedFrames;
 	HIPCHK( hipGetLastError() );
@@ -2859,6 +2862,49 @@ int rt_hip_kernel_times( rt_hip_ctx *c, float ms[5], int launches[5] )
 	return rt_hip_kernel_times_ex( c, ms, launches, nullptr );
 }
 
+// Launch intervals of one timed frame in ms after the frame's own start event.  Only the end of
+// every kernel is recorded (see enqueue_frame); a kernel starts when the last of its predecessors
+// has ended: the kernel before it on its stream and, where its stream waited for an event, the
+// kernel that event follows.  a[j][k] .. b[j][k]: kernel j (0 closest-hit, 1 shadow, 2 lighting) of
+// slot k; fold[2], frame end.  (The gap between a predecessor's end and the actual start of the
+// next kernel - a few microseconds of dispatch - is counted as the kernel's.)
+struct FrameTimes { float a[3][RT_MAX_SLOTS], b[3][RT_MAX_SLOTS], fold[2], end; };
+static int frame_times( rt_hip_ctx *c, int slotOfRing, FrameTimes &ft )
+{
+	hipEvent_t *ev = c->ev[slotOfRing];
+	const bool overlap = c->evOverlap[slotOfRing];
+	const int n = c->timedSlots;
+	hipEvent_t zero = ev[6 * RT_MAX_SLOTS + 2];
+	auto at = [&]( hipEvent_t e, float &t ) -> int { HIPCHK( hipEventElapsedTime( &t, zero, e ) ); return 0; };
+	float first = 0.0f;
+	if ( at( ev[0], first ) ) return 1;
+	for ( int k = 0; k < n; ++k )
+		for ( int j = 0; j < 3; ++j )
+			if ( at( ev[6 * k + 2 * j + 1], ft.b[j][k] ) ) return 1;
+	if ( at( ev[6 * RT_MAX_SLOTS + 3], ft.end ) ) return 1;
+	auto later = []( float x, float y ) { return x > y ? x : y; };
+	for ( int k = 0; k < n; ++k )
+	{
+		if ( overlap )
+		{
+			// chain on the caller's stream; shadow / lighting of slot k on auxiliary stream k % RT_AUX_STREAMS
+			ft.a[0][k] = k ? ft.b[0][k - 1] : first;
+			ft.a[1][k] = k >= RT_AUX_STREAMS ? later( ft.b[0][k], ft.b[2][k - RT_AUX_STREAMS] ) : ft.b[0][k];
+		}
+		else
+		{
+			ft.a[0][k] = k ? ft.b[2][k - 1] : first;
+			ft.a[1][k] = ft.b[0][k];
+		}
+		ft.a[2][k] = ft.b[1][k];
+	}
+	ft.fold[0] = n ? ft.b[0][n - 1] : first;
+	for ( int k = 0; k < n; ++k )
+		ft.fold[0] = later( ft.fold[0], ft.b[2][k] );
+	ft.fold[1] = ft.end;
+	return 0;
+}
+
 // Every launch of the frames rendered with RT_HIP_TIMING since the last read-out, as an interval
 // [start, end] in milliseconds after the start of the oldest such frame of `origin` (a context on
 // the same GPU; `c` itself when null): contexts that render frames side by side are brought onto
@@ -2880,23 +2926,19 @@ int rt_hip_kernel_intervals( rt_hip_ctx *c, rt_hip_ctx *origin, float *startEnd,
 	const int frames = c->timedFrames < RT_TIMED_FRAMES ? c->timedFrames : RT_TIMED_FRAMES;
 	if ( frames * ( 3 * n + 2 ) > cap ) return fail( "rt_hip_kernel_intervals: room for %d intervals, %d needed", cap, frames * ( 3 * n + 2 ) );
 	int m = 0;
-	auto put = [&]( hipEvent_t a, hipEvent_t b, int what ) -> int
-	{
-		float t0 = 0.0f, dt = 0.0f;
-		HIPCHK( hipEventElapsedTime( &t0, zero, a ) );
-		HIPCHK( hipEventElapsedTime( &dt, a, b ) );
-		startEnd[2 * m] = t0; startEnd[2 * m + 1] = t0 + dt; kind[m] = what;
-		++m;
-		return 0;
-	};
+	auto put = [&]( float a, float b, int what ) { startEnd[2 * m] = a; startEnd[2 * m + 1] = b; kind[m] = what; ++m; };
 	for ( int f = frames - 1; f >= 0; --f )
 	{
-		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
+		const int ring = ( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES;
+		FrameTimes ft;
+		if ( frame_times( c, ring, ft ) ) return 1;
+		float t0 = 0.0f;
+		HIPCHK( hipEventElapsedTime( &t0, zero, c->ev[ring][6 * RT_MAX_SLOTS + 2] ) );
 		for ( int k = 0; k < n; ++k )
 			for ( int j = 0; j < 3; ++j )
-				if ( put( ev[6 * k + 2 * j], ev[6 * k + 2 * j + 1], j ) ) return 1;
-		if ( put( ev[6 * RT_MAX_SLOTS], ev[6 * RT_MAX_SLOTS + 1], 3 ) ) return 1;
-		if ( put( ev[6 * RT_MAX_SLOTS + 2], ev[6 * RT_MAX_SLOTS + 3], 4 ) ) return 1;
+				put( t0 + ft.a[j][k], t0 + ft.b[j][k], j );
+		put( t0 + ft.fold[0], t0 + ft.fold[1], 3 );
+		put( t0, t0 + ft.end, 4 );
 	}
 	*count = m;
 	return 0;
@@ -2914,22 +2956,16 @@ int rt_hip_kernel_times_ex( rt_hip_ctx *c, float ms[5], int launches[5], float w
 	const int frames = c->timedFrames < RT_TIMED_FRAMES ? c->timedFrames : RT_TIMED_FRAMES;
 	for ( int f = 0; f < frames; ++f )
 	{
-		hipEvent_t *ev = c->ev[( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES];
-		hipEvent_t frame0 = ev[6 * RT_MAX_SLOTS + 2];
-		float t = 0.0f;
+		FrameTimes ft;
+		if ( frame_times( c, ( c->timedFrames - 1 - f ) % RT_TIMED_FRAMES, ft ) ) return 1;
 		for ( int j = 0; j < 3; ++j )             // closest, shadow, light
 		{
-			// launch intervals of this kernel relative to the start of the frame
 			float a[RT_MAX_SLOTS], b[RT_MAX_SLOTS];
 			for ( int k = 0; k < n; ++k )
 			{
-				HIPCHK( hipEventElapsedTime( &t, ev[6 * k + 2 * j], ev[6 * k + 2 * j + 1] ) );
-				ms[j] += t;
-				if ( wall )
-				{
-					HIPCHK( hipEventElapsedTime( &a[k], frame0, ev[6 * k + 2 * j] ) );
-					b[k] = a[k] + t;
-				}
+				a[k] = ft.a[j][k];
+				b[k] = ft.b[j][k];
+				ms[j] += b[k] - a[k];
 			}
 			if ( wall )
 			{
@@ -2950,11 +2986,9 @@ int rt_hip_kernel_times_ex( rt_hip_ctx *c, float ms[5], int launches[5], float w
 				}
 			}
 		}
-		HIPCHK( hipEventElapsedTime( &t, ev[6 * RT_MAX_SLOTS], ev[6 * RT_MAX_SLOTS + 1] ) );
-		ms[3] += t;
-		if ( wall ) wall[3] += t;
-		HIPCHK( hipEventElapsedTime( &t, ev[6 * RT_MAX_SLOTS + 2], ev[6 * RT_MAX_SLOTS + 3] ) );
-		ms[4] += t;
+		ms[3] += ft.fold[1] - ft.fold[0];
+		if ( wall ) wall[3] += ft.fold[1] - ft.fold[0];
+		ms[4] += ft.end;
 	}
 	for ( int i = 0; i < 5; ++i ) ms[i] /= (float) frames;
 	if ( wall ) for ( int i = 0; i < 4; ++i ) wall[i] /= (float) frames;
