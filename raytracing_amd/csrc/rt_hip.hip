@@ -651,9 +651,6 @@ DEVI void alpha_tri( const DevScene &S, const TriRay &R, const Rec &rc, const Tr
 // contains T likewise.  This needs ordered distances, so rays parallel to an
 // axis (see axis_parallel) never walk cooperatively.
 // ---------------------------------------------------------------------------
-#ifndef RT_COOP_POP
-#define RT_COOP_POP 64u       // sub-trees a segment takes off the stack at a time (at most its free lanes)
-#endif
 
 #ifdef RT_PROFILE_CHUNKS
 struct Prof { uint32_t lock, coop, iters; unsigned long long tExpand, tScan, tCoop, tDescend, tLeaf; };
@@ -669,8 +666,8 @@ struct Prof { uint32_t lock, coop, iters; unsigned long long tExpand, tScan, tCo
 #define PROF_T0( v ) ( (void) 0 )
 #define PROF_ADD( f, v ) ( (void) 0 )
 #endif
-// exchange area of the expand step: 5 words per lane, [word * RT_BLOCK + thread]
-__shared__ uint32_t g_lds_xch[5 * RT_BLOCK];
+// exchange area of the expand step: one (node, exit distance) pair per lane
+__shared__ uint2 g_lds_xch[RT_BLOCK];
 // rank -> lane of the rays still walking, one table per wave
 __shared__ uint32_t g_lds_owner[RT_BLOCK];
 
@@ -703,154 +700,113 @@ DEVI Seg make_seg( uint32_t q )
 	return g;
 }
 
-// One entry of a segment: node `cur` with its two words (once loaded) and the
-// interval of the ray inside it.  RT_SEG_LOAD in cur = words not loaded yet.
-#define RT_SEG_LOAD 0x80000000u
-struct SegEntry { uint32_t cur, nx, ny; float tN, tF; };
+// What a lane holds after the expand step: a leaf (its two node words) and the
+// interval of the ray inside it.
+struct SegLeaf { uint2 n; float tN, tF; };
+
+// the value the lane before mine holds (lane 0: unspecified)
+DEVI float lane_before( float x )
+{
+	return __uint_as_float( (uint32_t) __builtin_amdgcn_update_dpp( 0, (int) __float_as_uint( x ), 0x138 /* wave_shr:1 */, 0xf, 0xf, false ) );
+}
 
 // Expand (see above).  In: the ray of my segment (sr), its entry distance T,
 // the number of entries on its stack (sp, in the LDS column of thread
 // `col`), restart = begin at the root over [T, tEnd] instead.  Out: lanes with
 // `have` hold a leaf each, in walk order; sp = what is left on the stack;
 // lost = the stack did not fit (its content is void, the ray restarts).
+//
+// A segment and the stack behind it are ONE sequence of sub-trees in walk order
+// whose intervals follow each other without gaps (the exit distance of one is
+// the entry distance of the next; the first one starts at T).  An entry is
+// therefore a (node, exit distance) pair, the format of a stack entry, and an
+// iteration is: every lane replaces its node by the children the ray passes
+// through (a leaf stays), the new sequence is written in order - the first q
+// entries to the exchange area, the rest back onto the stack, farthest first -,
+// and every lane reads the entry of its position; positions behind the end of
+// the sequence are filled from the top of the stack.  The node words are
+// loaded after the exchange.
 template <bool STATS>
 DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn, float T, float tEnd, bool restart, uint32_t col, uint32_t cap,
-	SegEntry &en, bool &have, uint32_t &sp, bool &lost, Tally &tl PROF_ARG )
+	SegLeaf &lf, bool &have, uint32_t &sp, bool &lost, Tally &tl PROF_ARG )
 {
-	uint32_t *const xw = g_lds_xch + threadIdx.x;                  // my own slot
-	uint32_t *const xs = g_lds_xch + ( threadIdx.x - g.j );         // slot 0 of my segment
-	const uint2 *const stk = g_lds_stack + col;                    // entry k of the ray's stack: stk[k * RT_BLOCK]
-	uint2 *const stkw = g_lds_stack + col;
+	uint2 *const xs = g_lds_xch + ( threadIdx.x - g.j );           // slot 0 of my segment
+	uint2 *const stk = g_lds_stack + col;                          // entry k of the ray's stack: stk[k * RT_BLOCK]
 	lost = false;
-	uint32_t kept = 0u;
-	have = false;
-	en.cur = 0u; en.nx = 0u; en.ny = 3u; en.tN = T; en.tF = tEnd;
-	if ( segOn && restart )
-	{
+	have = segOn && restart && g.j == 0u;                          // a restarted ray begins with the root
+	if ( restart || !segOn )
 		sp = 0u;
-		kept = 1u;
-		if ( g.j == 0u )
-		{
-			have = true;
-			en.cur = RT_SEG_LOAD;                                      // the root
-		}
-	}
-	for ( ;; )
+	uint32_t cur = 0u;
+	float tN = T, tF = tEnd;
+	uint2 n = make_uint2( 0u, 3u );
+	if ( have )
 	{
-		// words of new entries
-		const bool fetch = have && ( en.cur & RT_SEG_LOAD ) != 0u;
-		if ( fetch )
-		{
-			en.cur &= ~RT_SEG_LOAD;
-			const uint2 n = S.nodes[en.cur];
-			en.nx = n.x;
-			en.ny = n.y;
-			if ( STATS ) ++tl.nodes;
-		}
-		const bool inner = have && ( en.ny & 3u ) != 3u;
-		const bool segInner = ( __ballot( inner ) & g.mask ) != 0ull;
-		// a segment of leaves with room takes sub-trees off the stack
-		uint32_t take = 0u;
-		if ( segOn && !segInner && !lost )
-		{
-			take = g.q - kept;
-			if ( take > sp ) take = sp;
-			if ( take > RT_COOP_POP ) take = RT_COOP_POP;
-		}
-		if ( __ballot( segInner || take != 0u ) == 0ull )
-			break;
-		PROF_INC( iters );
-		// exit distance of the entry before me (entry distance of a sub-tree that joins behind it)
-		const float prevF = shfl_f( en.tF, ( g.start + ( kept ? kept - 1u : 0u ) ) & 63u );
-		if ( segInner )
-		{
-			// my entry becomes one or two entries
-			uint32_t c0 = en.cur, x0 = en.nx, y0 = en.ny, c1 = 0u, oc = have ? 1u : 0u;
-			float a0 = en.tN, b0 = en.tF, a1 = 0.0f, b1 = 0.0f;
-			if ( inner )
-			{
-				const uint32_t axis = en.ny & 3u;
-				const float sep = __uint_as_float( en.nx );
-				const float o = pick( axis, sr.src.x, sr.src.y, sr.src.z );
-				const float iv = pick( axis, sr.inv.x, sr.inv.y, sr.inv.z );
-				const float d = pick( axis, sr.dest.x, sr.dest.y, sr.dest.z );
-				const float tSplit = ( sep - o ) * iv;
-				uint32_t nearN = en.cur + 1u, farN = en.ny >> 2;
-				if ( d < 0.0f )
-				{
-					const uint32_t tmp = nearN;
-					nearN = farN;
-					farN = tmp;
-				}
-				if ( tSplit >= en.tF )
-					c0 = nearN | RT_SEG_LOAD;
-				else if ( tSplit <= en.tN )
-					c0 = farN | RT_SEG_LOAD;
-				else
-				{
-					c0 = nearN | RT_SEG_LOAD;
-					b0 = tSplit;
-					c1 = farN | RT_SEG_LOAD;
-					a1 = tSplit;
-					b1 = en.tF;
-					oc = 2u;
-				}
-			}
-			const unsigned long long m1 = __ballot( segInner && oc >= 1u ), m2 = __ballot( segInner && oc == 2u );
-			const uint32_t pos = (uint32_t) ( __popcll( m1 & g.below ) + __popcll( m2 & g.below ) );
-			const uint32_t total = (uint32_t) ( __popcll( m1 & g.mask ) + __popcll( m2 & g.mask ) );
-			// what does not fit goes back onto the stack, farthest first
-			const uint32_t over = total > g.q ? total - g.q : 0u;
-			if ( sp + over > cap )
-				lost = true;
-			if ( oc >= 1u )
-			{
-				if ( pos < g.q )
-				{
-					uint32_t *w = xs + pos;
-					w[0] = c0; w[RT_BLOCK] = x0; w[2 * RT_BLOCK] = y0; w[3 * RT_BLOCK] = __float_as_uint( a0 ); w[4 * RT_BLOCK] = __float_as_uint( b0 );
-				}
-				else if ( !lost )
-					stkw[( sp + total - 1u - pos ) * RT_BLOCK] = make_uint2( c0 & ~RT_SEG_LOAD, __float_as_uint( b0 ) );
-			}
-			if ( oc == 2u )
-			{
-				if ( pos + 1u < g.q )
-				{
-					uint32_t *w = xs + pos + 1u;
-					w[0] = c1; w[RT_BLOCK] = 0u; w[2 * RT_BLOCK] = 0u; w[3 * RT_BLOCK] = __float_as_uint( a1 ); w[4 * RT_BLOCK] = __float_as_uint( b1 );
-				}
-				else if ( !lost )
-					stkw[( sp + total - 2u - pos ) * RT_BLOCK] = make_uint2( c1 & ~RT_SEG_LOAD, __float_as_uint( b1 ) );
-			}
-			sp = lost ? 0u : sp + over;
-			kept = total < g.q ? total : g.q;
-			wave_lds_sync();
-			have = g.j < kept;
-			if ( have )
-			{
-				en.cur = xw[0]; en.nx = xw[RT_BLOCK]; en.ny = xw[2 * RT_BLOCK];
-				en.tN = __uint_as_float( xw[3 * RT_BLOCK] );
-				en.tF = __uint_as_float( xw[4 * RT_BLOCK] );
-			}
-			wave_lds_sync();
-		}
-		else if ( take != 0u )
-		{
-			// lanes kept .. kept + take - 1 take the top `take` entries, nearest (top) first
-			if ( g.j >= kept && g.j < kept + take )
-			{
-				const uint32_t k = g.j - kept;
-				const uint2 e = stk[( sp - 1u - k ) * RT_BLOCK];
-				en.cur = e.x | RT_SEG_LOAD;
-				en.tF = __uint_as_float( e.y );
-				en.tN = k ? __uint_as_float( stk[( sp - k ) * RT_BLOCK].y ) : ( kept ? prevF : T );
-				have = true;
-			}
-			sp -= take;
-			kept += take;
-		}
+		n = S.nodes[0];
+		if ( STATS ) ++tl.nodes;
 	}
+	do
+	{
+		PROF_INC( iters );
+		// the kd step of my node, CL/rt_funcs_primitives.cl:185-251
+		const bool inner = have && ( n.y & 3u ) != 3u;
+		const uint32_t axis = n.y & 3u;
+		const float sep = __uint_as_float( n.x );
+		const float o = pick( axis, sr.src.x, sr.src.y, sr.src.z );
+		const float iv = pick( axis, sr.inv.x, sr.inv.y, sr.inv.z );
+		const float d = pick( axis, sr.dest.x, sr.dest.y, sr.dest.z );
+		const float tSplit = ( sep - o ) * iv;
+		const bool back = d < 0.0f;
+		const uint32_t left = cur + 1u, right = n.y >> 2;
+		const uint32_t nearN = back ? right : left, farN = back ? left : right;
+		const bool onlyNear = tSplit >= tF;
+		const bool onlyFar = !onlyNear && tSplit <= tN;
+		const bool two = inner && !onlyNear && !onlyFar;
+		// bit 31 marks an entry whose node has not been counted yet (counting build)
+		const uint32_t fresh = STATS ? 0x80000000u : 0u;
+		const uint32_t c0 = inner ? ( ( onlyFar ? farN : nearN ) | fresh ) : cur;
+		const float b0 = two ? tSplit : tF;
+		// my place in the new sequence
+		const unsigned long long m1 = __ballot( have ), m2 = __ballot( two );
+		const uint32_t pos = (uint32_t) ( __popcll( m1 & g.below ) + __popcll( m2 & g.below ) );
+		const uint32_t total = (uint32_t) ( __popcll( m1 & g.mask ) + __popcll( m2 & g.mask ) );
+		const uint32_t inSeg = total < g.q ? total : g.q;
+		const uint32_t over = total - inSeg;
+		uint32_t take = g.q - inSeg;                                  // free lanes take sub-trees off the stack
+		if ( take > sp ) take = sp;
+		if ( sp + over > cap )
+			lost = true;
+		const uint32_t top = sp + total - 1u;                         // position p >= q goes to stack entry top - p
+		if ( have && ( pos < g.q || !lost ) )
+		{
+			uint2 *const w = pos < g.q ? xs + pos : stk + ( top - pos ) * RT_BLOCK;
+			*w = make_uint2( c0, __float_as_uint( b0 ) );
+		}
+		if ( two && ( pos + 1u < g.q || !lost ) )
+		{
+			uint2 *const w = pos + 1u < g.q ? xs + pos + 1u : stk + ( top - pos - 1u ) * RT_BLOCK;
+			*w = make_uint2( farN | fresh, __float_as_uint( tF ) );
+		}
+		wave_lds_sync();
+		have = g.j < inSeg + take;
+		uint2 e = make_uint2( 0u, 0u );
+		if ( have )
+			e = g.j < inSeg ? xs[g.j] : stk[( sp - 1u - ( g.j - inSeg ) ) * RT_BLOCK];
+		wave_lds_sync();
+		if ( STATS && have && ( g.j >= inSeg || ( e.x >> 31 ) ) ) ++tl.nodes;
+		cur = STATS ? e.x & 0x7fffffffu : e.x;
+		tF = __uint_as_float( e.y );
+		sp = lost ? 0u : sp + over - take;
+		tN = lane_before( tF );
+		if ( g.j == 0u )
+			tN = T;
+		n = make_uint2( 0u, 3u );
+		if ( have )
+			n = S.nodes[cur];
+	}
+	while ( __ballot( have && ( n.y & 3u ) != 3u ) != 0ull );
+	lf.n = n;
+	lf.tN = tN;
+	lf.tF = tF;
 }
 
 // Continues the closest-hit query of every lane with `active` set
@@ -909,7 +865,7 @@ DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav
 			(void) box_ray( S, sr, tn, sEnd );                 // the ray did hit the box when it started
 		}
 
-		SegEntry en;
+		SegLeaf en;
 		bool have, lost;
 		PROF_T0( pe );
 		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl PROF_PASS );
@@ -920,10 +876,10 @@ DEVI void nearest_coop( const DevScene &S, const Ray &r, bool active, const Trav
 		const TriRay R = tri_ray( sr.src, sr.dest );
 		float lt = INFINITY;
 		NearHit lh = { INFINITY, 0.0f, 0.0f, 0u, 0 };
-		const uint32_t cnt = have ? en.ny >> 2 : 0u;
+		const uint32_t cnt = have ? en.n.y >> 2 : 0u;
 		if ( cnt != 0u )
 		{
-			uint32_t i = en.nx;
+			uint32_t i = en.n.x;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
 			for ( ;; )
@@ -1040,7 +996,7 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 			if ( sD < sEnd ) sEnd = sD;
 		}
 
-		SegEntry en;
+		SegLeaf en;
 		bool have, lost;
 		seg_expand<STATS>( S, g, sr, segOn, sT, sEnd, sRestart, ( threadIdx.x & ~63u ) + owner, cap, en, have, sSp, lost, tl PROF_PASS );
 
@@ -1049,10 +1005,10 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 		const TriRay R = tri_ray( sr.src, sr.dest );
 		uint32_t nh = 0u;
 		float a0 = 0.0f, a1 = 0.0f;
-		const uint32_t cnt = have ? en.ny >> 2 : 0u;
+		const uint32_t cnt = have ? en.n.y >> 2 : 0u;
 		for ( uint32_t i = 0u; i < cnt; ++i )
 		{
-			const Rec rc = load_rec( S.recs, en.nx + i );
+			const Rec rc = load_rec( S.recs, en.n.x + i );
 			float tt, u, v;
 			if ( STATS ) { ++tl.tris; tl.triSlots += lane_share(); }
 			if ( ray_tri( R, rc, tt, u, v ) && ( tt < sD ) && ( tt < en.tF ) && ( tt > en.tN ) )
@@ -1081,7 +1037,7 @@ DEVI void alpha_coop( const DevScene &S, const Ray &r, bool active, const Trav &
 				{
 					for ( uint32_t i = 0u; i < cnt; ++i )
 					{
-						const Rec rc = load_rec( S.recs, en.nx + i );
+						const Rec rc = load_rec( S.recs, en.n.x + i );
 						float tt, u, v;
 						if ( ray_tri( R, rc, tt, u, v ) && ( tt < sD ) && ( tt < en.tF ) && ( tt > en.tN ) )
 							sum += S.mats[rec_mat( rc )].color.a;
