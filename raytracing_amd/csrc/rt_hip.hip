@@ -736,7 +736,7 @@ DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn
 	have = segOn && restart && g.j == 0u;                          // a restarted ray begins with the root
 	if ( restart || !segOn )
 		sp = 0u;
-	uint32_t cur = 0u;
+	uint32_t cur = 0u, kept = segOn && restart ? 1u : 0u;
 	float tN = T, tF = tEnd;
 	uint2 n = make_uint2( 0u, 3u );
 	if ( have )
@@ -766,9 +766,10 @@ DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn
 		const uint32_t c0 = inner ? ( ( onlyFar ? farN : nearN ) | fresh ) : cur;
 		const float b0 = two ? tSplit : tF;
 		// my place in the new sequence
-		const unsigned long long m1 = __ballot( have ), m2 = __ballot( two );
-		const uint32_t pos = (uint32_t) ( __popcll( m1 & g.below ) + __popcll( m2 & g.below ) );
-		const uint32_t total = (uint32_t) ( __popcll( m1 & g.mask ) + __popcll( m2 & g.mask ) );
+		// (the lanes that hold an entry are the first `kept` of the segment)
+		const unsigned long long m2 = __ballot( two );
+		const uint32_t pos = g.j + (uint32_t) __popcll( m2 & g.below );
+		const uint32_t total = kept + (uint32_t) __popcll( m2 & g.mask );
 		const uint32_t inSeg = total < g.q ? total : g.q;
 		const uint32_t over = total - inSeg;
 		uint32_t take = g.q - inSeg;                                  // free lanes take sub-trees off the stack
@@ -787,7 +788,8 @@ DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn
 			*w = make_uint2( farN | fresh, __float_as_uint( tF ) );
 		}
 		wave_lds_sync();
-		have = g.j < inSeg + take;
+		kept = inSeg + take;
+		have = g.j < kept;
 		uint2 e = make_uint2( 0u, 0u );
 		if ( have )
 			e = g.j < inSeg ? xs[g.j] : stk[( sp - 1u - ( g.j - inSeg ) ) * RT_BLOCK];
