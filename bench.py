@@ -54,6 +54,11 @@ MALL_PEAK_GBS = 8600.0
 # run-time parameters (the reference's fixed depth 10 leaves ~2000 triangles
 # per leaf on this scene)
 TREE_DEPTH, TREE_LEAF = 26, 12
+# Leaves keep only the triangles that reach their cell (nodes and split planes stay the reference's; the
+# reference files a triangle under every leaf its bounding box overlaps).  Same frame, pixel for pixel and hit
+# id for hit id (tests/test_parity_gpu.py: test_pruned_leaves_give_the_frame_of_the_reference_leaves), with a
+# quarter fewer triangle tests per ray.  --prune-leaves 0 renders the reference's leaf lists.
+PRUNE_LEAVES = 1e-5
 ORBIT_FRAMES = 240
 
 WORKLOADS = {
@@ -94,7 +99,8 @@ def committed_counters(args, kernel, world):
         t = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
     except (OSError, ValueError):
         return None
-    key = f"{args.workload}/depth{args.depth}/leaf{args.leaf}/gpus{world}/{'serial' if args.no_overlap else 'overlap'}"
+    key = (f"{args.workload}/depth{args.depth}/leaf{args.leaf}{'/pruned' if args.prune_leaves > 0 else ''}/gpus{world}/"
+           f"{'serial' if args.no_overlap else 'overlap'}")
     return t.get(key, {}).get("k_" + kernel)
 
 
@@ -142,6 +148,8 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--depth", type=int, default=TREE_DEPTH)
     ap.add_argument("--leaf", type=int, default=TREE_LEAF)
+    ap.add_argument("--prune-leaves", type=float, default=PRUNE_LEAVES,
+                    help="margin (x scene size) of the leaf pruning of the host builder; 0 = the reference's leaf lists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy (1-GPU runs of a frame workload)")
     ap.add_argument("--timed-only", action="store_true",
@@ -188,15 +196,21 @@ def main():
     sc = wl["make"]()
     v, t = sc.flatten()
     t0 = time.time()
-    tree = FlatTree.build(v, t, args.depth, args.leaf)
+    tree = FlatTree.build(v, t, args.depth, args.leaf, prune_leaves=args.prune_leaves)
     build_s = time.time() - t0
+    ref_refs = len(tree.recs)
+    if args.prune_leaves > 0:
+        plain = FlatTree.build(v, t, args.depth, args.leaf)
+        assert len(plain.nodes) == len(tree.nodes) and len(plain.recs) >= len(tree.recs)
+        ref_refs = len(plain.recs)
+        plain.release()
 
     # the same tree built on the GPU (outside the timed region; reported, and checked against the host tree)
     DeviceTree.build(v, t, args.depth, args.leaf).release()
     t0 = time.time()
     dtree = DeviceTree.build(v, t, args.depth, args.leaf)
     gpu_build_s = time.time() - t0
-    assert (dtree.n_nodes, dtree.n_recs) == (len(tree.nodes), len(tree.recs))
+    assert (dtree.n_nodes, dtree.n_recs) == (len(tree.nodes), ref_refs)        # (the GPU builder keeps the reference's leaf lists)
     dtree.release()
 
     split = world > 1 and not sequence
@@ -232,6 +246,35 @@ def main():
     r = slots[0].r
     rows = r.local_rows
     frame_local = slots[0].frame_local
+
+    # ---- pruned leaf lists are only used when they give the frame of the reference's lists: this rank's share of
+    # the first frame is rendered once with each (a context of its own for the reference's lists) and every pixel
+    # compared on the device, outside the timed region
+    if args.prune_leaves > 0 and len(tree.recs) < ref_refs:
+        cam0 = scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world(rank % ORBIT_FRAMES, ORBIT_FRAMES)) if sequence else None
+        frames = []
+        for which in ("pruned", "reference"):
+            if which == "pruned":
+                rr = r
+            else:
+                plain = FlatTree.build(v, t, args.depth, args.leaf)
+                rr = HipRenderer(local_dev)
+                rr.load_scene(sc, plain)
+                if split:
+                    rr.set_tile(rdist.BAND_H, world, rank)
+            if cam0 is not None:
+                rr.set_camera(cam0)
+            out = torch.zeros_like(frame_local)
+            torch.cuda.synchronize()
+            rr.render(0, d_out=out.data_ptr())
+            rr.sync()
+            frames.append(out)
+            if which == "reference":
+                rr.close()
+                plain.release()
+        if not torch.equal(frames[0], frames[1]):
+            raise SystemExit("the pruned leaf lists change this frame: run with --prune-leaves 0")
+        del frames
 
     # ---- frame exchange of the split frame: the library's own RCCL gather (one communicator per frame in flight);
     # torch.distributed's gather (also RCCL) only where that cannot run (gloo rehearsals on one GPU) or fails to
@@ -447,6 +490,10 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['text']}",
                        "kd_tree": {"max_depth": args.depth, "max_prims_in_leaf": args.leaf, "depth": int(tree.depth),
                                    "nodes": int(len(tree.nodes)), "triangle_refs": int(len(tree.recs)),
+                                   "triangle_refs_reference_leaves": int(ref_refs),
+                                   "leaves": ("the reference's lists" if args.prune_leaves <= 0 else
+                                              f"reference nodes; a leaf lists only the triangles that touch its cell grown by "
+                                              f"{args.prune_leaves:g} x scene size (same frame, fewer tests)"),
                                    "host_build_s": round(build_s, 3), "gpu_build_s": round(gpu_build_s, 4)},
                        "schedule": "passes in order on one stream" if args.no_overlap else
                                    "closest-hit chain on the main stream, shadow + lighting passes on two auxiliary "

@@ -31,19 +31,35 @@ typedef struct _rt_kdtree_flat
 	int depth;                /* deepest leaf, root = 0 */
 } rt_kdtree_flat;
 
-/* Builder options.  With sahStop = 0 and allAxes = 0 the tree is the
- * reference's for the given limits.  The two extras (no reference
+/* Builder options.  With sahStop = 0, allAxes = 0 and pruneLeaves = 0 the tree
+ * is the reference's for the given limits.  The extras (no reference
  * counterpart) trade tree equality for traversal speed:
  *   sahStop > 0  make a leaf when the best split costs >= sahStop x the cost
  *                of not splitting (the reference always splits down to
  *                maxPrims / maxDepth, which multiplies triangle references)
  *   allAxes = 1  evaluate the 32 candidates on all three axes instead of the
- *                longest one only */
+ *                longest one only
+ *   pruneLeaves > 0  nodes and split planes stay the reference's; a leaf keeps
+ *                only the triangles that touch its cell grown by pruneLeaves x
+ *                the scene size on every side (exact triangle / box test in
+ *                double precision), in their original order.  The reference
+ *                files a triangle under every leaf its bounding box overlaps;
+ *                a triangle that does not come near a cell cannot be hit
+ *                inside the cell's distance interval, so closest hits and
+ *                shadow sums are unchanged while fewer triangles are tested.
+ *                (If the reference's partition dropped a triangle - one that
+ *                lies in a split plane goes to neither child - the result of
+ *                the walk depends on leaves that list a triangle they do not
+ *                contain; such a tree keeps the reference's lists.)
+ *                The margin has to cover the rounding of hit and split
+ *                distances: 1e-5 is about 170 units in the last place of a
+ *                coordinate at the scene's scale. */
 typedef struct _rt_kdtree_build_opts
 {
 	int   maxDepth, maxPrims, threads;
 	float sahStop;
 	int   allAxes;
+	float pruneLeaves;
 } rt_kdtree_build_opts;
 
 int  rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,

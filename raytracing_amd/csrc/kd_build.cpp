@@ -6,6 +6,7 @@
 // child boxes, and therefore the tree, are the reference's bit for bit.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -163,7 +164,60 @@ struct BNode
 	int depth = 0;                   // deepest leaf below, relative to this node
 };
 
-struct Task { BNode *node; std::vector<uint32_t> prims; rt_box box; int depth; };
+// lo / hi: the node's cell given by the scene box and the split planes above it (the
+// planes themselves, not the rounded centre / half size of `box`)
+struct Cell { float lo[3], hi[3]; };
+struct Task { BNode *node; std::vector<uint32_t> prims; rt_box box; int depth; Cell cell; };
+
+// Does the triangle touch the cell grown by `pad` on every side?  Separating-axis
+// test (3 cell normals, the triangle's normal, 9 edge cross products) in double
+// precision; answers "yes" in every doubtful case.
+bool tri_touches_cell( const rt_vector3 &q0, const rt_vector3 &q1, const rt_vector3 &q2, const Cell &c, double pad )
+{
+	double bc[3], bh[3], a[3][3];
+	const float *q[3] = { &q0.x, &q1.x, &q2.x };
+	for ( int k = 0; k < 3; ++k )
+	{
+		bc[k] = 0.5 * ( (double) c.lo[k] + (double) c.hi[k] );
+		bh[k] = 0.5 * ( (double) c.hi[k] - (double) c.lo[k] ) + pad;
+		for ( int v = 0; v < 3; ++v )
+			a[v][k] = (double) q[v][k] - bc[k];
+	}
+	for ( int k = 0; k < 3; ++k )
+	{
+		const double mn = std::min( a[0][k], std::min( a[1][k], a[2][k] ) ), mx = std::max( a[0][k], std::max( a[1][k], a[2][k] ) );
+		if ( !( mn <= bh[k] && mx >= -bh[k] ) )
+			return mn != mn || mx != mx;                  // apart, unless a coordinate is not a number: keep
+	}
+	double e[3][3];
+	for ( int k = 0; k < 3; ++k )
+	{
+		e[0][k] = a[1][k] - a[0][k];
+		e[1][k] = a[2][k] - a[1][k];
+		e[2][k] = a[0][k] - a[2][k];
+	}
+	// triangle plane
+	{
+		const double n[3] = { e[0][1] * -e[2][2] - e[0][2] * -e[2][1], e[0][2] * -e[2][0] - e[0][0] * -e[2][2], e[0][0] * -e[2][1] - e[0][1] * -e[2][0] };
+		const double d = n[0] * a[0][0] + n[1] * a[0][1] + n[2] * a[0][2];
+		const double r = std::fabs( n[0] ) * bh[0] + std::fabs( n[1] ) * bh[1] + std::fabs( n[2] ) * bh[2];
+		if ( std::fabs( d ) > r )
+			return false;
+	}
+	// unit axis k x edge f
+	for ( int f = 0; f < 3; ++f )
+		for ( int k = 0; k < 3; ++k )
+		{
+			const int k1 = ( k + 1 ) % 3, k2 = ( k + 2 ) % 3;
+			// u_k x e = (component k1: -e[k2], component k2: e[k1])
+			const double ax1 = -e[f][k2], ax2 = e[f][k1];
+			const double p0 = ax1 * a[0][k1] + ax2 * a[0][k2], p1 = ax1 * a[1][k1] + ax2 * a[1][k2], p2 = ax1 * a[2][k1] + ax2 * a[2][k2];
+			const double r = std::fabs( ax1 ) * bh[k1] + std::fabs( ax2 ) * bh[k2];
+			if ( std::min( p0, std::min( p1, p2 ) ) > r || std::max( p0, std::max( p1, p2 ) ) < -r )
+				return false;
+		}
+	return true;
+}
 
 struct Pool
 {
@@ -180,6 +234,31 @@ struct Builder
 	int maxDepth, maxPrims;
 	float sahStop = 0.0f;      // > 0: leaf when bestCost >= sahStop * leafCost (not in the reference)
 	int allAxes = 0;           // 1: try all three axes, keep the cheapest (not in the reference)
+	// > 0: a leaf keeps only the triangles that touch its cell grown by pruneLeaves x the scene size
+	// (not in the reference, whose leaves hold every triangle whose bounding box overlaps the cell)
+	float pruneLeaves = 0.0f;
+	double prunePad = 0.0;
+	const rt_vertex *verts = nullptr;
+	const rt_triangle *tris = nullptr;
+	std::atomic<uint64_t> dropped{ 0 }, lostInPlane{ 0 };
+
+	void make_leaf( BNode *node, std::vector<uint32_t> &prims, const Cell &cell )
+	{
+		node->leaf = true;
+		if ( pruneLeaves > 0.0f )
+		{
+			size_t k = 0;
+			for ( size_t i = 0; i < prims.size(); ++i )
+			{
+				const rt_triangle &t = tris[prims[i]];
+				if ( tri_touches_cell( verts[t.pV0].pos, verts[t.pV1].pos, verts[t.pV2].pos, cell, prunePad ) )
+					prims[k++] = prims[i];
+			}
+			dropped.fetch_add( prims.size() - k, std::memory_order_relaxed );
+			prims.resize( k );
+		}
+		node->prims.swap( prims );
+	}
 	Pool pool;
 	size_t spawnThreshold = 2048;
 	// Running totals: triangles that cannot be separated double their references
@@ -190,7 +269,7 @@ struct Builder
 	std::atomic<bool> tooBig{ false };
 	static constexpr uint64_t LIMIT = 1ull << 30;
 
-	void split( BNode *node, std::vector<uint32_t> &prims, const rt_box &box, int depth, bool mayspawn )
+	void split( BNode *node, std::vector<uint32_t> &prims, const rt_box &box, int depth, bool mayspawn, const Cell &cell )
 	{
 		const uint64_t n = prims.size();
 		if ( tooBig.load( std::memory_order_relaxed ) )
@@ -200,8 +279,7 @@ struct Builder
 		}
 		if ( n <= (uint64_t) maxPrims || depth == maxDepth )
 		{
-			node->leaf = true;
-			node->prims.swap( prims );
+			make_leaf( node, prims, cell );
 			if ( leafRefs.fetch_add( n, std::memory_order_relaxed ) + n >= LIMIT )
 				tooBig.store( true, std::memory_order_relaxed );
 			return;
@@ -230,8 +308,7 @@ struct Builder
 			}
 		if ( sahStop > 0.0f && best >= sahStop * leafCost )
 		{
-			node->leaf = true;
-			node->prims.swap( prims );
+			make_leaf( node, prims, cell );
 			return;
 		}
 		const float *mnA = tmin[ax], *mxA = tmax[ax];
@@ -239,16 +316,24 @@ struct Builder
 		std::vector<uint32_t> pl, pr;
 		pl.reserve( cl );
 		pr.reserve( cr );
+		uint64_t neither = 0;
 		for ( uint64_t i = 0; i < n; ++i )        // stable partition (:971-1029)
 		{
 			const uint32_t p = pp[i];
-			if ( mnA[p] < sep ) pl.push_back( p );
-			if ( mxA[p] > sep ) pr.push_back( p );
+			const bool toL = mnA[p] < sep, toR = mxA[p] > sep;
+			if ( toL ) pl.push_back( p );
+			if ( toR ) pr.push_back( p );
+			neither += !toL && !toR;
 		}
+		if ( neither )                            // (a triangle lying in the split plane goes to neither child)
+			lostInPlane.fetch_add( neither, std::memory_order_relaxed );
 		std::vector<uint32_t>().swap( prims );
 
 		rt_box bl, br;
 		child_boxes( box, ax, sep, bl, br );
+		Cell cl2 = cell, cr2 = cell;
+		cl2.hi[ax] = sep;
+		cr2.lo[ax] = sep;
 		node->sep = sep;
 		node->axis = ax;
 		node->l = new BNode();
@@ -261,16 +346,16 @@ struct Builder
 			// hand the right sub-tree to another worker, keep the left one
 			{
 				std::lock_guard<std::mutex> g( pool.mu );
-				pool.q.push_back( Task{ node->r, std::move( pr ), br, depth + 1 } );
+				pool.q.push_back( Task{ node->r, std::move( pr ), br, depth + 1, cr2 } );
 				++pool.pending;
 			}
 			pool.cv.notify_one();
-			split( node->l, pl, bl, depth + 1, true );
+			split( node->l, pl, bl, depth + 1, true, cl2 );
 		}
 		else
 		{
-			split( node->l, pl, bl, depth + 1, mayspawn );
-			split( node->r, pr, br, depth + 1, mayspawn );
+			split( node->l, pl, bl, depth + 1, mayspawn, cl2 );
+			split( node->r, pr, br, depth + 1, mayspawn, cr2 );
 		}
 	}
 
@@ -287,7 +372,7 @@ struct Builder
 				t = std::move( pool.q.front() );
 				pool.q.pop_front();
 			}
-			split( t.node, t.prims, t.box, t.depth, true );
+			split( t.node, t.prims, t.box, t.depth, true, t.cell );
 			{
 				std::lock_guard<std::mutex> g( pool.mu );
 				--pool.pending;
@@ -496,12 +581,28 @@ extern "C" int rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangl
 	b.maxPrims = maxPrims;
 	b.sahStop = opts->sahStop;
 	b.allAxes = opts->allAxes;
+	b.pruneLeaves = opts->pruneLeaves > 0.0f ? opts->pruneLeaves : 0.0f;
+	b.verts = verts;
+	b.tris = tris;
+	Cell rootCell;
+	{
+		const float c[3] = { out->bbox.center.x, out->bbox.center.y, out->bbox.center.z };
+		const float e[3] = { out->bbox.extents.x, out->bbox.extents.y, out->bbox.extents.z };
+		double size = 0.0;
+		for ( int k = 0; k < 3; ++k )
+		{
+			rootCell.lo[k] = c[k] - e[k];
+			rootCell.hi[k] = c[k] + e[k];
+			size = std::max( size, std::fabs( (double) c[k] ) + std::fabs( (double) e[k] ) );
+		}
+		b.prunePad = (double) b.pruneLeaves * size;
+	}
 
 	BNode *root = new BNode();
 	{
 		std::vector<uint32_t> all( nT );
 		for ( uint64_t i = 0; i < nT; ++i ) all[i] = (uint32_t) i;
-		b.pool.q.push_back( Task{ root, std::move( all ), out->bbox, 0 } );
+		b.pool.q.push_back( Task{ root, std::move( all ), out->bbox, 0, rootCell } );
 		b.pool.pending = 1;
 	}
 	if ( threads > 1 && nT >= 4 * b.spawnThreshold )
@@ -514,6 +615,17 @@ extern "C" int rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangl
 	else
 		b.worker();
 
+	// Pruning relies on every triangle being listed by every leaf it reaches.  The reference's
+	// partition drops a triangle that lies in the split plane from both children, and what such a
+	// tree then returns depends on the leaves that list the triangle without containing it (a hit
+	// in front of a leaf's interval is accepted).  Such a tree keeps the reference's leaf lists.
+	if ( b.pruneLeaves > 0.0f && b.lostInPlane.load() != 0 )
+	{
+		release_tree( root );
+		rt_kdtree_build_opts plain = *opts;
+		plain.pruneLeaves = 0.0f;
+		return rt_kdtree_build_flat_ex( verts, tris, vertexCount, trianglesCount, &plain, out );
+	}
 	totals( root );
 	if ( b.tooBig.load() || root->nodes >= ( 1ull << 30 ) || root->refs >= ( 1ull << 30 ) )
 	{

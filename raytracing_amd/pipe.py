@@ -107,13 +107,14 @@ class FlatTree:
         self.depth = struct.depth
 
     @classmethod
-    def build(cls, verts, tris, max_depth=10, max_prims=7, threads=0, sah_stop=0.0, all_axes=0):
-        """sah_stop / all_axes = 0 gives the reference's tree for the limits."""
+    def build(cls, verts, tris, max_depth=10, max_prims=7, threads=0, sah_stop=0.0, all_axes=0, prune_leaves=0.0):
+        """sah_stop / all_axes / prune_leaves = 0 gives the reference's tree for the limits;
+        prune_leaves > 0 (1e-4) keeps its nodes and drops leaf references that cannot be hit."""
         from ._lib import BuildOpts
         verts = np.ascontiguousarray(verts, T.vertex)
         tris = np.ascontiguousarray(tris, T.triangle)
         s = _FlatTreeStruct()
-        o = BuildOpts(max_depth, max_prims, threads, sah_stop, all_axes)
+        o = BuildOpts(max_depth, max_prims, threads, sah_stop, all_axes, prune_leaves)
         rc = lib().rt_kdtree_build_flat_ex(_p(verts), _p(tris), C.c_uint64(len(verts)),
                                            C.c_uint64(len(tris)), C.byref(o), C.byref(s))
         if rc:

@@ -25,9 +25,9 @@ pytestmark = pytest.mark.gpu
 IMG = image_scenes()
 
 
-def hip_render(sc, depth=10, prims=7, flags=RT_HIP_HITIDS | RT_HIP_STATS, tile=None, params=()):
+def hip_render(sc, depth=10, prims=7, flags=RT_HIP_HITIDS | RT_HIP_STATS, tile=None, params=(), prune=0.0):
     v, t = sc.flatten()
-    tree = FlatTree.build(v, t, depth, prims)
+    tree = FlatTree.build(v, t, depth, prims, prune_leaves=prune)
     r = HipRenderer(0)
     r.load_scene(sc, tree)
     if tile:
@@ -396,6 +396,28 @@ def test_config3_4k_sampled_against_oracle(depth, prims, flags):
     assert sc.w * sc.h <= st["raysClosest"] <= 5 * sc.w * sc.h
     assert st["raysShadow"] == st["hits"] <= st["raysClosest"]
     tree.release()
+
+
+@pytest.mark.parametrize("which", ["config3", "config5", "glass", "default"])
+def test_pruned_leaves_give_the_frame_of_the_reference_leaves(which):
+    """bench.py renders a tree whose leaves hold only the triangles that reach
+    their cell (pruneLeaves = 1e-5, same nodes): every pixel and every primary
+    hit id must be what the reference's leaf lists give, at full size; for the
+    benchmark frame additionally a lattice against the oracle walking the
+    REFERENCE leaves."""
+    sc, depth, prims = {"config3": (scenes.config3(), 26, 12), "config5": (scenes.config5_frame(101), 26, 12),
+                        "glass": IMG["sphere16k_glass"][:1] + (20, 3), "default": (scenes.default_scene(), 18, 6)}[which]
+    a = hip_render(sc, depth, prims, flags=RT_HIP_HITIDS)
+    b = hip_render(sc, depth, prims, flags=RT_HIP_HITIDS | RT_HIP_STATS, prune=1e-5)
+    assert len(b[3].recs) < len(a[3].recs) and len(b[3].nodes) == len(a[3].nodes)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    if which == "config3":
+        nodes, idx = a[3].expand()
+        oimg, oid, ost = orc.raytrace(sc, a[3].bbox, nodes, idx, x0=5, x_step=24, y0=17, y_step=24)
+        m = np.zeros(b[1].shape, bool)
+        m[17::24, 5::24] = True
+        same, exact = assert_parity(b[0], b[1], oimg, oid, m)
+        assert same == 1.0 and exact == 1.0
 
 
 def test_config5_4k_frame_sampled_against_oracle():

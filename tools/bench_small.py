@@ -8,7 +8,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "config3"
 depth, leaf, frames = (int(x) for x in (sys.argv[2:5] + ["28", "16", "3"][len(sys.argv[2:5]):]))
 sc = getattr(scenes, name)()
 v, t = sc.flatten()
-tree = FlatTree.build(v, t, depth, leaf)
+tree = FlatTree.build(v, t, depth, leaf, prune_leaves=float(os.environ.get("RT_PRUNE", "1e-5")))    # as bench.py builds it
 r = HipRenderer(0)
 r.load_scene(sc, tree)
 if os.environ.get("RT_OVERLAP") is not None:

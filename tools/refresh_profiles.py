@@ -1,11 +1,11 @@
 """Copies the results of tools/profile_round.sh <tag> from gpurun_out/<tag>/ into profiles/ under the
 round's prefix: kernel stats, counter summaries, the two bench lines, and <round>_counters.json, the per-kernel
 table bench.py quotes (fabric traffic per launch and the ratios that show what binds a kernel).
-Usage: python tools/refresh_profiles.py <tag> <round> [workload/depthD/leafL/gpusN]"""
+Usage: python tools/refresh_profiles.py <tag> <round> [workload/depthD/leafL[/pruned]/gpusN]"""
 import csv, glob, json, os, shutil, subprocess, sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
-key = sys.argv[3] if len(sys.argv) > 3 else "config3/depth26/leaf12/gpus1"
+key = sys.argv[3] if len(sys.argv) > 3 else "config3/depth26/leaf12/pruned/gpus1"
 src = os.path.join("gpurun_out", tag)
 shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], f"profiles/{rnd}_kernel_stats.csv")
 shutil.copy(src + "/bench.json", f"profiles/{rnd}_bench_config3.json")

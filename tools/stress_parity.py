@@ -2,7 +2,10 @@
 helper; the committed tests hold a fixed subset): random triangle soups with
 spheres and lights, random materials (opaque / transparent / reflective),
 random tree limits, ray budgets, overlap on and off, band splits.
+With RT_PRUNE=<margin> the GPU renders the tree with pruned leaf lists
+(pruneLeaves of the host builder) while the oracle walks the reference's.
 Usage: python tools/stress_parity.py [first_seed] [count]"""
+import os
 import sys
 import numpy as np
 from oracle import orc
@@ -59,6 +62,9 @@ for seed in range(first, first + count):
         continue
     nodes, idx = tree.expand()
     oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
+    if float(os.environ.get("RT_PRUNE", "0")) > 0:
+        tree.release()
+        tree = FlatTree.build(vv, tt, depth, prims, prune_leaves=float(os.environ["RT_PRUNE"]))
     r = HipRenderer(0)
     r.load_scene(sc, tree)
     r.set_param(RT_PARAM_STACK_SIZE, sc.stack_size)

@@ -15,7 +15,7 @@ def main():
         stop = combo[2] if len(combo) > 2 else 0.0
         axes = int(combo[3]) if len(combo) > 3 else 0
         t0 = time.time()
-        tree = FlatTree.build(v, t, depth, leaf, 0, stop, axes)
+        tree = FlatTree.build(v, t, depth, leaf, 0, stop, axes, float(os.environ.get("RT_PRUNE", "1e-5")))
         tb = time.time() - t0
         r.load_scene(sc, tree)
         if os.environ.get("RT_PARTS"):
