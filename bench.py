@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy (1-GPU runs of a frame workload)")
     ap.add_argument("--timed-only", action="store_true",
                     help="for profiler runs: every launch of the frame kernels belongs to the warm-up or the timed steps (no "
-                         "frame-alone latency, no in-order pass, no proxy), so a profiler's per-kernel average is the timed "
+                         "frame-alone latency, no in-order pass, no proxy, no check of the pruned leaves), so a profiler's per-kernel average is the timed "
                          "region's avg_launch_ms")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
@@ -250,7 +250,7 @@ def main():
     # ---- pruned leaf lists are only used when they give the frame of the reference's lists: this rank's share of
     # the first frame is rendered once with each (a context of its own for the reference's lists) and every pixel
     # compared on the device, outside the timed region
-    if args.prune_leaves > 0 and len(tree.recs) < ref_refs:
+    if args.prune_leaves > 0 and len(tree.recs) < ref_refs and not args.timed_only:
         cam0 = scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world(rank % ORBIT_FRAMES, ORBIT_FRAMES)) if sequence else None
         frames = []
         for which in ("pruned", "reference"):

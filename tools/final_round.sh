@@ -1,0 +1,12 @@
+#!/bin/bash
+# Everything a round's profiles/ are refreshed from, in one GPU call: the GPU tests, tools/profile_round.sh <tag>,
+# and the bench lines of the other two workloads.   tools/final_round.sh <tag>
+TAG=${1:-r02}
+export PYTHONPATH=. TMPDIR=/tmp
+mkdir -p gpurun_out/$TAG
+timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/$TAG/gputests.log 2>&1 || { tail -5 gpurun_out/$TAG/gputests.log; exit 1; }
+tail -1 gpurun_out/$TAG/gputests.log
+tools/profile_round.sh $TAG || exit 1
+timeout -k 10 300 python3 -u bench.py --workload config2 --depth 22 --leaf 12 > gpurun_out/$TAG/bench_config2.json 2> gpurun_out/$TAG/bench_config2.err || exit 1
+timeout -k 10 400 python3 -u bench.py --workload config5 > gpurun_out/$TAG/bench_config5.json 2> gpurun_out/$TAG/bench_config5.err || exit 1
+echo final_round done
