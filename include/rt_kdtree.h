@@ -65,8 +65,12 @@ typedef struct _rt_kdtree_build_opts
 int  rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, rt_kdtree_flat *out );
 
-/* Returns 0 on success.  threads <= 0 picks the number of online CPUs
- * (capped at 16).  Triangle vertex indices must be global and < vertexCount. */
+/* Returns 0 on success (1 bad arguments, 2 limits out of range, 3 vertex index
+ * out of range, 4 tree too large: beyond the 30-bit links of a node, or beyond
+ * a quarter of the machine's memory / 32 GiB while it is being built - triangles
+ * that cannot be separated double their references with every level).
+ * threads <= 0 picks the number of online CPUs (capped at 16).  Triangle vertex
+ * indices must be global and < vertexCount. */
 int  rt_kdtree_build_flat( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, int maxDepth, int maxPrims, int threads, rt_kdtree_flat *out );
 void rt_kdtree_flat_release( rt_kdtree_flat *t );

@@ -268,6 +268,21 @@ struct Builder
 	std::atomic<uint64_t> madeNodes{ 1 }, leafRefs{ 0 };
 	std::atomic<bool> tooBig{ false };
 	static constexpr uint64_t LIMIT = 1ull << 30;
+	// ... and beyond the machine: a node of the tree under construction takes about 96 bytes, a
+	// reference 4 (twice that while it is being partitioned).  A quarter of the physical memory,
+	// at most 32 GiB, is what a build may take.
+	uint64_t memBudget = mem_budget();
+	static uint64_t mem_budget()
+	{
+		const long pages = sysconf( _SC_PHYS_PAGES ), sz = sysconf( _SC_PAGE_SIZE );
+		uint64_t b = pages > 0 && sz > 0 ? (uint64_t) pages * (uint64_t) sz / 4u : 8ull << 30;
+		return std::min<uint64_t>( b, 32ull << 30 );
+	}
+	void account()
+	{
+		if ( madeNodes.load( std::memory_order_relaxed ) * 96u + leafRefs.load( std::memory_order_relaxed ) * 8u > memBudget )
+			tooBig.store( true, std::memory_order_relaxed );
+	}
 
 	void split( BNode *node, std::vector<uint32_t> &prims, const rt_box &box, int depth, bool mayspawn, const Cell &cell )
 	{
@@ -340,6 +355,7 @@ struct Builder
 		node->r = new BNode();
 		if ( madeNodes.fetch_add( 2, std::memory_order_relaxed ) + 2 >= LIMIT )
 			tooBig.store( true, std::memory_order_relaxed );
+		account();
 
 		if ( mayspawn && pr.size() >= spawnThreshold && pl.size() >= spawnThreshold )
 		{
@@ -630,7 +646,7 @@ extern "C" int rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangl
 	if ( b.tooBig.load() || root->nodes >= ( 1ull << 30 ) || root->refs >= ( 1ull << 30 ) )
 	{
 		release_tree( root );
-		return 4;          // 30-bit links of the 8-byte node
+		return 4;          // 30-bit links of the 8-byte node, or the memory a build may take
 	}
 	out->nNodes = root->nodes;
 	out->nRecs = root->refs;

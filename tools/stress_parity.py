@@ -55,6 +55,8 @@ for seed in range(first, first + count):
     vv, tt = sc.flatten()
     if n >= 3000:
         depth = min(depth, 20 if prims > 3 else 16)      # overlapping triangles cannot be separated: references double per level
+    elif n >= 400 and prims <= 3:
+        depth = min(depth, 20)
     try:
         tree = FlatTree.build(vv, tt, depth, prims)
     except Exception as e:          # tree beyond the 30-bit links: a legitimate refusal
