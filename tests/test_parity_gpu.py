@@ -408,7 +408,7 @@ def test_pruned_leaves_give_the_frame_of_the_reference_leaves(which):
     sc, depth, prims = {"config3": (scenes.config3(), 26, 12), "config5": (scenes.config5_frame(101), 26, 12),
                         "glass": IMG["sphere16k_glass"][:1] + (20, 3), "default": (scenes.default_scene(), 18, 6)}[which]
     a = hip_render(sc, depth, prims, flags=RT_HIP_HITIDS)
-    b = hip_render(sc, depth, prims, flags=RT_HIP_HITIDS | RT_HIP_STATS, prune=1e-5)
+    b = hip_render(sc, depth, prims, flags=RT_HIP_HITIDS, prune=1e-5)           # (the kernels bench.py times: no counting code)
     assert len(b[3].recs) < len(a[3].recs) and len(b[3].nodes) == len(a[3].nodes)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     if which == "config3":
