@@ -48,7 +48,14 @@
 #include "rt_hip.h"
 #include "rt_kdtree.h"
 
-#define RT_BLOCK      256
+// One wave per workgroup: the persistent kernels of a frame overlap in their tails, and a
+// workgroup can only start where all its waves find room at once and gives its LDS back only
+// when its last wave has ended.  With four waves per workgroup the step time of the benchmark
+// frame is 6.14 ms, with two 6.06 ms, with one 5.56 ms (nothing in a frame kernel needs more
+// than a wave: no barriers, LDS per wave).
+#ifndef RT_BLOCK
+#define RT_BLOCK      64
+#endif
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK  12     // traversal stack entries per lane kept in LDS
 #endif
@@ -76,7 +83,7 @@
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
 #define RT_TIMED_FRAMES 32
 #ifndef RT_AUX_OCC
-#define RT_AUX_OCC    4      // blocks per CU of a shadow pass that runs beside the closest-hit chain
+#define RT_AUX_OCC    ( 1024 / RT_BLOCK )      // workgroups per CU of a shadow pass that runs beside the closest-hit chain (16 waves)
 #endif
 #ifndef RT_AUX_STREAMS
 #define RT_AUX_STREAMS 2      // auxiliary streams the shadow / lighting passes are dealt to
@@ -101,7 +108,7 @@
 #define RT_COOP_MIN_SHIFT 3u
 #endif
 #ifndef RT_STREAM_OCC
-#define RT_STREAM_OCC 4      // blocks per CU of the streaming (non-traversal) passes
+#define RT_STREAM_OCC ( 1024 / RT_BLOCK )      // workgroups per CU of the streaming (non-traversal) passes (16 waves)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -2590,13 +2597,13 @@ int rt_hip_sync( rt_hip_ctx *c )
 // bounded by its own counter, every per-pixel record is written before it is
 // read).
 // ---------------------------------------------------------------------------
-#define RT_NOALLOC_GRID 128              // workgroups per persistent launch (sizes the stack-overflow strip)
+#define RT_NOALLOC_GRID ( 32768 / RT_BLOCK )      // workgroups per persistent launch: 512 waves (sizes the stack-overflow strip)
 
 constexpr size_t noalloc_align( size_t x ) { return ( x + 255 ) & ~(size_t) 255; }
 struct NoallocLayout
 {
 	// entries per list: no launch here uses block reservations (they start at
-	// RT_NOALLOC_GRID * 4 * 256 = 131072 entries per list), so a list holds at most one entry per pixel
+	// 512 waves x 256 = 131072 entries per list), so a list holds at most one entry per pixel
 	static constexpr size_t cap = RT_HIP_NOALLOC_MAX_PIXELS + 64;
 	static constexpr size_t npix = RT_HIP_NOALLOC_MAX_PIXELS;
 	static constexpr size_t slots = RT_HIP_NOALLOC_MAX_SLOTS, lights = RT_HIP_NOALLOC_MAX_LIGHTS;
