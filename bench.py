@@ -28,9 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# A frame runs on three streams (closest-hit chain + two auxiliary ones) and two frames are in
+# A frame runs on three streams (closest-hit chain + two auxiliary ones) and three frames are in
 # flight; with the null stream (the kd-tree builder's) and the collective library's streams a rank
-# uses nine to twelve.  The runtime's default of four hardware queues per process folds several
+# uses ten to fourteen.  The runtime's default of four hardware queues per process folds several
 # streams into one queue, which serialises what is meant to overlap: measured, a frame of two in
 # flight costs 7.2 ms at 8 queues (one stream too few) and 6.8 ms from 10 on.  Must be set before
 # the HIP runtime starts (the machine exports 4, hence an assignment).
@@ -162,8 +162,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
                          "buffers, one shared scene), so a frame's sparse last passes overlap the next frame's first ones.  "
-                         "0 = by the size of a rank's share: 2 for half a frame or more (a third one gains nothing: 6.85 "
-                         "against 6.79 ms), 3 for a quarter or less (1/8 frame: 1.31 against 1.39 ms)")
+                         "0 = 3 (full frame 5.55 / 5.37 / 5.61 ms with 2 / 3 / 4 in flight, 1/8 frame 1.36 / 1.08 / 1.08 ms, "
+                         "fly-through frame 31.2 / 31.0 ms, 1080p frame 0.91 / 0.81 ms)")
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -216,7 +216,7 @@ def main():
     split = world > 1 and not sequence
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world) if split else sc.h
     def slots_for(parts):
-        return max(1, min(args.in_flight, 4)) if args.in_flight else (2 if parts <= 2 or sequence else 3)
+        return max(1, min(args.in_flight, 4)) if args.in_flight else 3
 
     n_slots = slots_for(world if split else 1)
     # (the strong-scaling proxy of a single-rank run renders quarter and eighth shares: one more context for those)

@@ -48,11 +48,12 @@
 #include "rt_hip.h"
 #include "rt_kdtree.h"
 
-// One wave per workgroup: the persistent kernels of a frame overlap in their tails, and a
+// One wave per workgroup: the persistent kernels of the frames in flight overlap, and a
 // workgroup can only start where all its waves find room at once and gives its LDS back only
-// when its last wave has ended.  With four waves per workgroup the step time of the benchmark
-// frame is 6.14 ms, with two 6.06 ms, with one 5.56 ms (nothing in a frame kernel needs more
-// than a wave: no barriers, LDS per wave).
+// when its last wave has ended.  Step time of the benchmark frame, three frames in flight,
+// 8 waves per CU and launch (RT_OCC_CAP): 5.67 ms with four waves per workgroup, 5.52 ms with
+// two, 5.38 ms with one (nothing in a frame kernel needs more than a wave: no barriers, LDS
+// per wave).
 #ifndef RT_BLOCK
 #define RT_BLOCK      64
 #endif
@@ -106,6 +107,15 @@
 #endif
 #ifndef RT_COOP_MIN_SHIFT
 #define RT_COOP_MIN_SHIFT 3u
+#endif
+// Workgroups (= waves) per CU of one persistent launch.  Half of what fits (16): a launch that
+// takes every wave slot leaves none for the passes that run beside it and for the other frames in
+// flight, which then only get in as its waves retire.  One pass alone on the chip is a quarter
+// slower this way (closest-hit passes of a frame 4.6 -> 5.9 ms), the frames in flight together are
+// faster: step time with at most 4 / 6 / 8 / 10 / 12 / 16 waves per CU and launch: 5.76 / 5.46 /
+// 5.38 / 5.40 / 5.50 / 5.76 ms (a 1/8 frame: 1.09 / 1.04 / 1.08 / 1.09 / 1.10 / 1.05 ms).
+#ifndef RT_OCC_CAP
+#define RT_OCC_CAP 8
 #endif
 #ifndef RT_STREAM_OCC
 #define RT_STREAM_OCC ( 1024 / RT_BLOCK )      // workgroups per CU of the streaming (non-traversal) passes (16 waves)
@@ -2053,10 +2063,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	{
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
 			occ = 1;
-		if ( occ > 8 ) occ = 8;
-#ifdef RT_OCC_CAP
 		if ( occ > RT_OCC_CAP ) occ = RT_OCC_CAP;
-#endif
 		*k.dst = occ * c->numCU;
 		if ( k.occ ) *k.occ = occ;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
