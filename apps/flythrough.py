@@ -41,7 +41,7 @@ import numpy as np
 
 from raytracing_amd import dist as rdist
 from raytracing_amd import scenes
-from raytracing_amd.pipe import FlatTree, HipRenderer
+from raytracing_amd.pipe import RT_PARAM_LAUNCH_WAVES, FlatTree, HipRenderer
 
 
 def write_png(path, bgra):
@@ -86,6 +86,9 @@ def main():
         r = HipRenderer(local_rank)
         r.share_scene(rs[0], sc)                 # no second copy of the scene
         rs.append(r)
+    if n_slots > 1:
+        for r in rs:                             # frames in flight: a pass leaves half of every CU to the other frames' passes
+            r.set_param(RT_PARAM_LAUNCH_WAVES, 8)
     if not args.no_files:
         os.makedirs(args.out, exist_ok=True)
     mine = rdist.sequence_frames(args.frames, world, rank)

@@ -42,7 +42,8 @@ import torch.distributed as dist
 
 from raytracing_amd import dist as rdist
 from raytracing_amd import scenes
-from raytracing_amd.pipe import RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_OVERLAP, DeviceTree, FlatTree, HipRenderer
+from raytracing_amd.pipe import (RT_HIP_STATS, RT_HIP_TIMING, RT_PARAM_LAUNCH_WAVES, RT_PARAM_OVERLAP, DeviceTree, FlatTree,
+                                 HipRenderer)
 
 # roofs: HBM3E spec; L2 and Infinity Cache as measured chip-wide for gathered rows (the access
 # shape of this path), the upper end of the ranges
@@ -158,6 +159,8 @@ def main():
                          "region's avg_launch_ms")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
+    ap.add_argument("--launch-waves", type=int, default=0,
+                    help="waves per CU one traversal pass occupies (1..16); 0 = 8 with frames in flight, 16 with one")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
@@ -237,6 +240,9 @@ def main():
         else:
             sl.r.share_scene(slots[0].r, sc)
         sl.r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
+        # frames in flight: a pass takes half the wave slots of a CU, so that the passes of the other frames find room
+        # beside it (5.38 against 5.76 ms per step; a frame alone would be faster with all 16: 6.7 against 7.4 ms)
+        sl.r.set_param(RT_PARAM_LAUNCH_WAVES, args.launch_waves if args.launch_waves else (8 if n_built > 1 else 16))
         if split:
             sl.r.set_tile(rdist.BAND_H, world, rank)
         sl.frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
@@ -384,6 +390,8 @@ def main():
 
     # one frame on its own (nothing else in flight): the latency of a frame, as opposed to the step time
     lat = []
+    lone_waves = args.launch_waves if args.launch_waves else 16      # (a frame or a pass alone: every wave slot of a CU)
+    r.set_param(RT_PARAM_LAUNCH_WAVES, lone_waves)
     for _ in range(0 if args.timed_only else 5):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -425,6 +433,7 @@ def main():
         r.sync()
         kms_iso, _ = r.kernel_times()
         r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
+    r.set_param(RT_PARAM_LAUNCH_WAVES, args.launch_waves if args.launch_waves else (8 if n_built > 1 else 16))
 
     # ---- roofline of the dominant kernel (counting pass, outside the timed region)
     r.render(RT_HIP_STATS, d_out=frame_local.data_ptr())
@@ -502,6 +511,8 @@ def main():
                        "shadow_rays_per_step": int(cnt[1] / args.steps),
                        "frames_per_s": round(args.steps * (world if sequence else 1) / elapsed, 3),
                        "frames_in_flight": n_slots, "frame_latency_ms_alone": round(frame_latency_ms, 4) if lat else None,
+                       "waves_per_cu_and_pass": {"timed_region": args.launch_waves if args.launch_waves else (8 if n_built > 1 else 16),
+                                                 "frame_alone_and_isolated_passes": lone_waves},
                        "parallelism": "single GPU" if world == 1 else
                                       (f"frame f of the sequence on rank f mod {world}, scene replicated, no exchange" if sequence else
                                        f"frame split in bands of {rdist.BAND_H} rows over {world} GPUs, scene replicated, "

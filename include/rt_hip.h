@@ -104,6 +104,12 @@ typedef struct _rt_hip_stats
                                           12); a ray that needs more restarts its walk from the root.  Lower values
                                           exist to exercise that path.  Same image either way.                      */
 
+#define RT_PARAM_LAUNCH_WAVES       10   /* waves per compute unit that one traversal pass occupies (1..16, default 16 =
+                                          all that fit: a frame rendered on its own is fastest that way).  A caller
+                                          that keeps several frames in flight (contexts sharing a scene) sets 8: a
+                                          pass that takes every wave slot keeps the other frames' passes out until
+                                          its waves retire.  Same image either way.                                */
+
 #define RT_HIP_MAX_TREE_DEPTH 64       /* deepest tree the traversal stack admits */
 
 int  rt_hip_device_count( void );

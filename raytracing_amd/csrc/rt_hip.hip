@@ -108,14 +108,15 @@
 #ifndef RT_COOP_MIN_SHIFT
 #define RT_COOP_MIN_SHIFT 3u
 #endif
-// Workgroups (= waves) per CU of one persistent launch.  Half of what fits (16): a launch that
-// takes every wave slot leaves none for the passes that run beside it and for the other frames in
-// flight, which then only get in as its waves retire.  One pass alone on the chip is a quarter
-// slower this way (closest-hit passes of a frame 4.6 -> 5.9 ms), the frames in flight together are
-// faster: step time with at most 4 / 6 / 8 / 10 / 12 / 16 waves per CU and launch: 5.76 / 5.46 /
-// 5.38 / 5.40 / 5.50 / 5.76 ms (a 1/8 frame: 1.09 / 1.04 / 1.08 / 1.09 / 1.10 / 1.05 ms).
+// Waves per CU of one traversal pass (RT_PARAM_LAUNCH_WAVES; 16 fit).  A frame on its own is fastest
+// when every pass takes all of them (6.7 ms for the benchmark frame against 7.4 ms with 8).  With
+// frames in flight it is the other way round: a pass that takes every wave slot leaves none for the
+// passes beside it and for the other frames, which then only get in as its waves retire - step time
+// with three frames in flight and at most 4 / 6 / 8 / 10 / 12 / 16 waves per CU and pass: 5.76 / 5.46 /
+// 5.38 / 5.40 / 5.50 / 5.76 ms (a 1/8 frame: 1.09 / 1.04 / 1.08 / 1.09 / 1.10 / 1.05 ms).  The default
+// serves the caller that renders one frame at a time; callers that keep frames in flight ask for 8.
 #ifndef RT_OCC_CAP
-#define RT_OCC_CAP 8
+#define RT_OCC_CAP 16
 #endif
 #ifndef RT_STREAM_OCC
 #define RT_STREAM_OCC ( 1024 / RT_BLOCK )      // workgroups per CU of the streaming (non-traversal) passes (16 waves)
@@ -1960,6 +1961,7 @@ struct rt_hip_ctx
 	int overlap = 1;
 	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
+	int launchWaves = RT_OCC_CAP;                     // RT_PARAM_LAUNCH_WAVES
 	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
 	// [frame][(slot * 3 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop; of the
 	// start events only that of the first kernel is recorded (enqueue_frame, frame_times)
@@ -2063,7 +2065,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	{
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
 			occ = 1;
-		if ( occ > RT_OCC_CAP ) occ = RT_OCC_CAP;
+		if ( occ * ( RT_BLOCK / 64 ) > 16 ) occ = 16 / ( RT_BLOCK / 64 );
 		*k.dst = occ * c->numCU;
 		if ( k.occ ) *k.occ = occ;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
@@ -2076,6 +2078,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	if ( const char *v = getenv( "RT_COOP_SHADOW" ) ) c->coopShadow = atoi( v );
 	if ( const char *v = getenv( "RT_COOP_CLOSEST" ) ) c->coopClosest = atoi( v );
 	if ( const char *v = getenv( "RT_BIG_FRAME" ) ) c->bigFrame = (uint32_t) atoll( v );
+	if ( const char *v = getenv( "RT_LAUNCH_WAVES" ) ) if ( atoi( v ) >= 1 && atoi( v ) <= 16 ) c->launchWaves = atoi( v );
 	// a streaming pass gains nothing from more than a few waves per SIMD
 	if ( c->gridLight > RT_STREAM_OCC * c->numCU ) c->gridLight = RT_STREAM_OCC * c->numCU;
 
@@ -2383,6 +2386,12 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 		c->coopLive = value;
 		return 0;
 	}
+	if ( key == RT_PARAM_LAUNCH_WAVES )
+	{
+		if ( value < 1 || value > 16 ) return fail( "RT_PARAM_LAUNCH_WAVES must be 1..16" );
+		c->launchWaves = value;
+		return 0;
+	}
 	if ( key == RT_PARAM_COOP_STACK )
 	{
 		if ( value < 0 || value > RT_LDS_STACK ) return fail( "RT_PARAM_COOP_STACK must be 0..%d", RT_LDS_STACK );
@@ -2539,10 +2548,13 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 		Wx.coopCap = (uint32_t) c->coopCap;
 
 		// a persistent grid never needs more waves than there are chunks
-		const uint32_t want = k == 0 ? ( W.nChunks0 + 3u ) / 4u : 0u;
+		const uint32_t wpb = RT_BLOCK / 64u, want = k == 0 ? ( W.nChunks0 + wpb - 1u ) / wpb : 0u;
 		int gc = c->gridClosest[big][stats], gl = c->gridLight;
 		// beside the chain a shadow pass leaves part of every CU to it
 		int gw = overlap && c->occShadow[stats] > RT_AUX_OCC ? RT_AUX_OCC * c->numCU : c->gridShadow[stats];
+		const int most = c->launchWaves * c->numCU / ( RT_BLOCK / 64 );
+		if ( gc > most ) gc = most;
+		if ( gw > most ) gw = most;
 		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
 		if ( k == 0 && want * (uint32_t) lights < (uint32_t) gw ) gw = (int) ( want ? want * lights : 1u );
 		if ( k == 0 && want < (uint32_t) gl ) gl = (int) ( want ? want : 1u );

@@ -19,7 +19,7 @@ from ._lib import DeviceTreeStruct, RenderPipeStruct, RtError, Stats, check, lib
 RT_HIP_STATS, RT_HIP_HITIDS, RT_HIP_TIMING = 1, 2, 4
 (RT_PARAM_STACK_SIZE, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
  RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE, RT_PARAM_OVERLAP, RT_PARAM_GPU_BUILD,
- RT_PARAM_COOP_LIVE, RT_PARAM_COOP_STACK) = 1, 2, 3, 4, 5, 6, 7, 8, 9
+ RT_PARAM_COOP_LIVE, RT_PARAM_COOP_STACK, RT_PARAM_LAUNCH_WAVES) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 kdnode = np.dtype([("a", "<u4"), ("b", "<u4")])
 trirec = np.dtype([("nv0x", "<f4"), ("e1x", "<f4"), ("nv0y", "<f4"), ("e1y", "<f4"),

@@ -14,6 +14,7 @@ timeout -k 10 500 python3 -u bench.py > $OUT/bench.json 2> $OUT/bench.err || exi
 echo bench done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline --timed-only > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo stats done
+export RT_LAUNCH_WAVES=8      # the counter passes render one frame at a time; give the passes the grids of the timed region
 tools/pmc_passes.sh $OUT/pmc || exit 1
 RT_OVERLAP=0 tools/pmc_passes.sh $OUT/pmc_serial || exit 1
 echo profile_round done
