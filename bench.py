@@ -160,7 +160,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every pass of a frame on one stream, one after the other (kernel-isolated timings)")
     ap.add_argument("--launch-waves", type=int, default=0,
-                    help="waves per CU one traversal pass occupies (1..16); 0 = 8 with frames in flight, 16 with one")
+                    help="waves per CU one traversal pass occupies (1..16); 0 = 16 for one frame at a time, with frames in "
+                         "flight 8, and 6 for a rank's share of a quarter frame or less")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
@@ -221,6 +222,14 @@ def main():
     def slots_for(parts):
         return max(1, min(args.in_flight, 4)) if args.in_flight else 3
 
+    def waves_for(parts, contexts):
+        """Waves per CU one traversal pass occupies: all 16 for a frame on its own; with frames in flight 8, and 6 for
+        shares of a quarter frame and less (three in flight: full frame 5.53 / 5.40 / 5.43 ms with 6 / 8 / 10, 1/4 frame
+        1.66 / 1.68 / 1.68 ms, 1/8 frame 1.04 / 1.12 / 1.09 ms)."""
+        if args.launch_waves:
+            return args.launch_waves
+        return 16 if contexts <= 1 else (8 if parts <= 2 else 6)
+
     n_slots = slots_for(world if split else 1)
     # (the strong-scaling proxy of a single-rank run renders quarter and eighth shares: one more context for those)
     n_built = max(n_slots, slots_for(8)) if world == 1 and not sequence and not args.no_proxy and not args.timed_only else n_slots
@@ -240,9 +249,9 @@ def main():
         else:
             sl.r.share_scene(slots[0].r, sc)
         sl.r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
-        # frames in flight: a pass takes half the wave slots of a CU, so that the passes of the other frames find room
-        # beside it (5.38 against 5.76 ms per step; a frame alone would be faster with all 16: 6.7 against 7.4 ms)
-        sl.r.set_param(RT_PARAM_LAUNCH_WAVES, args.launch_waves if args.launch_waves else (8 if n_built > 1 else 16))
+        # frames in flight: a pass takes half the wave slots of a CU or less, so that the passes of the other frames find
+        # room beside it (5.38 against 5.76 ms per step; a frame alone would be faster with all 16: 6.7 against 7.4 ms)
+        sl.r.set_param(RT_PARAM_LAUNCH_WAVES, waves_for(world if split else 1, n_slots))
         if split:
             sl.r.set_tile(rdist.BAND_H, world, rank)
         sl.frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
@@ -433,7 +442,7 @@ def main():
         r.sync()
         kms_iso, _ = r.kernel_times()
         r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
-    r.set_param(RT_PARAM_LAUNCH_WAVES, args.launch_waves if args.launch_waves else (8 if n_built > 1 else 16))
+    r.set_param(RT_PARAM_LAUNCH_WAVES, waves_for(world if split else 1, n_slots))
 
     # ---- roofline of the dominant kernel (counting pass, outside the timed region)
     r.render(RT_HIP_STATS, d_out=frame_local.data_ptr())
@@ -467,6 +476,7 @@ def main():
             use = all_slots[:slots_for(parts)]
             outs = []
             for sl in use:
+                sl.r.set_param(RT_PARAM_LAUNCH_WAVES, waves_for(parts, len(use)))
                 sl.r.set_tile(rdist.BAND_H, parts, 0)
                 outs.append(torch.zeros((rdist.padded_rows(sc.h, rdist.BAND_H, parts), sc.w, 4), dtype=torch.uint8, device=dev))
             for i in range(2 * len(use)):
@@ -478,7 +488,9 @@ def main():
             torch.cuda.synchronize()
             proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 36 * 1e3, 4)
             proxy[f"part_0_of_{parts}_frames_in_flight"] = len(use)
+            proxy[f"part_0_of_{parts}_waves_per_cu_and_pass"] = waves_for(parts, len(use))
         for sl in all_slots:
+            sl.r.set_param(RT_PARAM_LAUNCH_WAVES, waves_for(world if split else 1, n_slots))
             sl.r.set_tile(rdist.BAND_H, 1, 0)
 
     if rank == 0:
@@ -511,7 +523,7 @@ def main():
                        "shadow_rays_per_step": int(cnt[1] / args.steps),
                        "frames_per_s": round(args.steps * (world if sequence else 1) / elapsed, 3),
                        "frames_in_flight": n_slots, "frame_latency_ms_alone": round(frame_latency_ms, 4) if lat else None,
-                       "waves_per_cu_and_pass": {"timed_region": args.launch_waves if args.launch_waves else (8 if n_built > 1 else 16),
+                       "waves_per_cu_and_pass": {"timed_region": waves_for(world if split else 1, n_slots),
                                                  "frame_alone_and_isolated_passes": lone_waves},
                        "parallelism": "single GPU" if world == 1 else
                                       (f"frame f of the sequence on rank f mod {world}, scene replicated, no exchange" if sequence else
