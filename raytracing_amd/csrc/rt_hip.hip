@@ -119,7 +119,7 @@
 #define RT_OCC_CAP 16
 #endif
 #ifndef RT_STREAM_OCC
-#define RT_STREAM_OCC ( 1024 / RT_BLOCK )      // workgroups per CU of the streaming (non-traversal) passes (16 waves)
+#define RT_STREAM_OCC ( 256 / RT_BLOCK )       // workgroups per CU of the streaming (non-traversal) passes: 4 waves (with 16, the lighting waves, 129 registers each, hold wave slots the traversal passes could use: 5.40 against 5.35 ms)
 #endif
 
 // ---------------------------------------------------------------------------
