@@ -496,6 +496,31 @@ def test_overlapped_and_in_order_schedules_give_the_same_frame():
         assert np.array_equal(img, out[0][0]) and np.array_equal(ids, out[0][1]) and n == out[0][2]
 
 
+def test_waves_per_pass_do_not_change_the_frame():
+    """RT_PARAM_LAUNCH_WAVES only sizes the persistent grids of the traversal passes (how many waves of a CU
+    one pass occupies); values outside 1..16 are refused."""
+    from raytracing_amd._lib import RtError
+    from raytracing_amd.pipe import RT_PARAM_LAUNCH_WAVES
+    sc, depth, prims = IMG["sphere16k_glass"]
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 20, 4)
+    r = HipRenderer(0)
+    r.load_scene(sc, tree)
+    out = []
+    for waves in (16, 1, 6, 8, 16):
+        r.set_param(RT_PARAM_LAUNCH_WAVES, waves)
+        r.render(RT_HIP_HITIDS | RT_HIP_STATS)
+        st = r.stats()
+        # (node visits are not compared: how many leaves the cooperative walk scans ahead depends on how a list is dealt out)
+        out.append((r.read_frame().copy(), r.read_hit_ids().copy(), st["raysClosest"], st["raysShadow"], st["hits"]))
+    for bad in (0, 17, -3):
+        with pytest.raises(RtError, match="RT_PARAM_LAUNCH_WAVES"):
+            r.set_param(RT_PARAM_LAUNCH_WAVES, bad)
+    r.close()
+    for img, ids, *counts in out[1:]:
+        assert np.array_equal(img, out[0][0]) and np.array_equal(ids, out[0][1]) and counts == list(out[0][2:])
+
+
 @pytest.mark.parametrize("frame", [0, 37, 121])
 def test_fly_through_frames_match_the_oracle(frame):
     """Config-5 style: camera on the orbit, reflective + refractive sphere, six rays per pixel."""
