@@ -8,7 +8,7 @@ f mod N (scene and tree replicated, no data-path collective) and written as
     python apps/flythrough.py --frames 240 --out pngs
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 apps/flythrough.py --frames 240
 
-Two frames are in flight on the GPU (two contexts that share the resident
+Three frames are in flight on the GPU (contexts that share the resident
 scene, one host thread each: render, then read back into a page-locked block),
 and the PNG encoding of finished frames runs on a pool of encoder threads
 beside the next frames' rendering (zlib releases the interpreter lock).
@@ -67,7 +67,10 @@ def main():
     ap.add_argument("--out", default="pngs")
     ap.add_argument("--no-files", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one frame at a time: render, read back, encode")
-    ap.add_argument("--in-flight", type=int, default=2, help="frames rendered side by side on the GPU")
+    ap.add_argument("--in-flight", type=int, default=3, help="frames rendered side by side on the GPU")
+    ap.add_argument("--prune-leaves", type=float, default=0.0,
+                    help="margin (x scene size) of the host builder's leaf pruning, e.g. 1e-5; 0 = the reference's leaf lists "
+                         "(pruned lists are not checked against them here: compare a frame of both once, as bench.py does)")
     ap.add_argument("--encoders", type=int, default=0, help="PNG encoder threads (default: host cores of this rank, at most 12)")
     args = ap.parse_args()
     w, h = (int(x) for x in args.size.split("x"))
@@ -79,7 +82,7 @@ def main():
 
     sc = scenes.config5_frame(0, w, h, args.lon, args.lat)
     v, t = sc.flatten()
-    tree = FlatTree.build(v, t, args.depth, args.leaf)
+    tree = FlatTree.build(v, t, args.depth, args.leaf, prune_leaves=args.prune_leaves)
     rs = [HipRenderer(local_rank)]
     rs[0].load_scene(sc, tree)                   # geometry and tree stay resident for the whole sequence
     for _ in range(1, n_slots):
