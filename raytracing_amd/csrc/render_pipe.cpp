@@ -382,6 +382,9 @@ void rt_render_pipe_set_param( rt_render_pipe *pRp, int key, int value )
 		im->haveTree = false;
 		break;
 	case RT_PARAM_OVERLAP:
+	case RT_PARAM_COOP_LIVE:
+	case RT_PARAM_COOP_STACK:
+	case RT_PARAM_LAUNCH_WAVES:
 		if ( rt_hip_set_param( im->hip, key, value ) )
 			die_hip( "rt_render_pipe_set_param" );
 		break;
