@@ -570,7 +570,7 @@ def test_fly_through_driver_single_rank(tmp_path, mode):
                          check=True, capture_output=True, text=True, timeout=300).stdout
     rec = json.loads(out.strip().splitlines()[-1])
     assert rec["frames"] == n and rec["rays_last_frame"] > 160 * 96
-    assert rec["frames_in_flight"] == (1 if mode == "serial" else 2)
+    assert rec["frames_in_flight"] == (1 if mode == "serial" else 3)
     assert sorted(os.listdir(tmp_path / "pngs"), key=lambda x: int(x[:-4])) == [f"{f + 8}.png" for f in range(n)]
     sc = scenes.config5_frame(0, 160, 96, 40, 20)
     v, t = sc.flatten()
