@@ -84,7 +84,7 @@
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
 #define RT_TIMED_FRAMES 32
 #ifndef RT_AUX_OCC
-#define RT_AUX_OCC    ( 1024 / RT_BLOCK )      // workgroups per CU of a shadow pass that runs beside the closest-hit chain (16 waves)
+#define RT_AUX_OCC    ( 1024 / RT_BLOCK )      // development knob: a tighter limit (workgroups per CU) for a shadow pass that runs beside the closest-hit chain; the default, 16 waves, never binds (RT_PARAM_LAUNCH_WAVES does)
 #endif
 #ifndef RT_AUX_STREAMS
 #define RT_AUX_STREAMS 2      // auxiliary streams the shadow / lighting passes are dealt to
