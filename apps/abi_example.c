@@ -98,6 +98,9 @@ int main( int argc, char **argv )
 	if ( rt_hip_share_scene( b, a ) ) return die( "rt_hip_share_scene" );
 	if ( rt_hip_set_camera( b, &cam ) || rt_hip_set_image( b, w, h ) || rt_hip_set_param( b, RT_PARAM_STACK_SIZE, 4 ) ) return die( "set up (second context)" );
 
+	/* frames in flight: a pass of either frame takes half the wave slots of a compute unit, so that the other frame's
+	 * passes find room beside it (the default, all 16, is for one frame at a time) */
+	if ( rt_hip_set_param( a, RT_PARAM_LAUNCH_WAVES, 8 ) || rt_hip_set_param( b, RT_PARAM_LAUNCH_WAVES, 8 ) ) return die( "RT_PARAM_LAUNCH_WAVES" );
 	/* two frames in flight: both are enqueued before either is read */
 	if ( rt_hip_render( a, NULL, 0 ) || rt_hip_render( b, NULL, 0 ) ) return die( "rt_hip_render" );
 	if ( rt_hip_read_frame( a, f0 ) || rt_hip_read_frame( b, f1 ) ) return die( "rt_hip_read_frame" );
