@@ -110,6 +110,14 @@ typedef struct _rt_hip_stats
                                           pass that takes every wave slot keeps the other frames' passes out until
                                           its waves retire.  Same image either way.                                */
 
+#define RT_PARAM_PRUNE_LEAVES       11   /* 1 = trees built from now on list in a leaf only the triangles that touch its
+                                          cell (margin RT_PRUNE_LEAVES_MARGIN x scene size; rt_kdtree.h, pruneLeaves):
+                                          rt_hip_build_tree, and both builders of the render pipe.  Default 0: the
+                                          reference's leaf lists.  Same frame on every scene tested, fewer triangle
+                                          tests; not exact for rays that start in a split plane with a direction
+                                          component of exactly zero.                                               */
+#define RT_PRUNE_LEAVES_MARGIN 1e-5f
+
 #define RT_HIP_MAX_TREE_DEPTH 64       /* deepest tree the traversal stack admits */
 
 int  rt_hip_device_count( void );

@@ -108,6 +108,14 @@ typedef struct _rt_kdtree_device
  * rt_kdtree_device_last_error).  hipStream: stream to build on, NULL = default. */
 int  rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, int maxDepth, int maxPrims, void *hipStream, rt_kdtree_device *out );
+/* The same with the builder options of the host builder.  Of the extras only
+ * pruneLeaves is available here (sahStop / allAxes: code 2): the leaf lists are
+ * pruned in place after the build - a leaf's record range keeps its start, its
+ * count drops, nRecs stays what it was - by the host builder's test applied to
+ * the vertices the records hold, and not at all when the build dropped a
+ * triangle that lies in a split plane.  No reference counterpart. */
+int  rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out );
 void rt_kdtree_device_release( rt_kdtree_device *t );
 /* copy a device tree to host arrays (malloc'ed; rt_kdtree_flat_release frees them) */
 int  rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_flat *out );

@@ -83,6 +83,7 @@ struct GeomInfo
 	uint32_t badIndex;     // some triangle names a vertex that does not exist
 	uint32_t maxMat;       // highest material slot (saturated to 32 bits)
 	float box[6];          // scene box: centre xyz, half extent xyz
+	uint32_t lostInPlane;  // references that went to neither child of a split (triangles lying in the split plane)
 };
 
 // Extents of every triangle; the index check and the highest material slot ride
@@ -467,7 +468,7 @@ struct RefFlags
 // becomes the k-th reference of its left child; leaves move to the leaf pool
 __global__ __launch_bounds__( TB ) void k_scatter( LevelTab L, RefFlags F, uint32_t nRefs,
 	const unsigned long long *scan, uint32_t *nextRefs, uint32_t *nextRefNode,
-	uint32_t *leafPool, uint32_t leafPoolBase )
+	uint32_t *leafPool, uint32_t leafPoolBase, uint32_t *lostInPlane )
 {
 	const uint32_t j = blockIdx.x * TB + threadIdx.x;
 	if ( j >= nRefs )
@@ -481,6 +482,8 @@ __global__ __launch_bounds__( TB ) void k_scatter( LevelTab L, RefFlags F, uint3
 	}
 	const unsigned long long f = F( j ), here = scan[j], base = scan[s0];
 	const uint32_t c = 2u * W.splitIdx( i );
+	if ( f == 0ull )
+		atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
 	if ( f & 1ull )
 	{
 		const uint32_t p = W.childStart( i ) + ( (uint32_t) here - (uint32_t) base );
@@ -594,6 +597,115 @@ __global__ __launch_bounds__( TB ) void k_shade_records( const rt_vertex *verts,
 	shade[i] = s;
 }
 
+// ---- pruned leaf lists (rt_kdtree_build_opts.pruneLeaves, see rt_kdtree.h) ----
+// Does the triangle touch the cell grown by `pad`?  Separating axes: the cell's
+// three normals, the triangle's normal, the nine edge cross products; "yes" in
+// every doubtful case (the same test as the host builder's).
+__device__ bool tri_touches_cell( const double q[3][3], const float lo[3], const float hi[3], double pad )
+{
+	double bc[3], bh[3], a[3][3];
+	for ( int k = 0; k < 3; ++k )
+	{
+		bc[k] = 0.5 * ( (double) lo[k] + (double) hi[k] );
+		bh[k] = 0.5 * ( (double) hi[k] - (double) lo[k] ) + pad;
+		for ( int v = 0; v < 3; ++v )
+			a[v][k] = q[v][k] - bc[k];
+	}
+	for ( int k = 0; k < 3; ++k )
+	{
+		const double mn = fmin( a[0][k], fmin( a[1][k], a[2][k] ) ), mx = fmax( a[0][k], fmax( a[1][k], a[2][k] ) );
+		const bool nan = a[0][k] != a[0][k] || a[1][k] != a[1][k] || a[2][k] != a[2][k];
+		if ( !( mn <= bh[k] && mx >= -bh[k] ) )
+			return nan;
+		if ( nan )
+			return true;
+	}
+	double e[3][3];
+	for ( int k = 0; k < 3; ++k )
+	{
+		e[0][k] = a[1][k] - a[0][k];
+		e[1][k] = a[2][k] - a[1][k];
+		e[2][k] = a[0][k] - a[2][k];
+	}
+	{
+		const double n[3] = { e[0][1] * -e[2][2] - e[0][2] * -e[2][1], e[0][2] * -e[2][0] - e[0][0] * -e[2][2], e[0][0] * -e[2][1] - e[0][1] * -e[2][0] };
+		const double d = n[0] * a[0][0] + n[1] * a[0][1] + n[2] * a[0][2];
+		const double r = fabs( n[0] ) * bh[0] + fabs( n[1] ) * bh[1] + fabs( n[2] ) * bh[2];
+		if ( fabs( d ) > r )
+			return false;
+	}
+	for ( int f = 0; f < 3; ++f )
+		for ( int k = 0; k < 3; ++k )
+		{
+			const int k1 = ( k + 1 ) % 3, k2 = ( k + 2 ) % 3;
+			const double ax1 = -e[f][k2], ax2 = e[f][k1];
+			const double p0 = ax1 * a[0][k1] + ax2 * a[0][k2], p1 = ax1 * a[1][k1] + ax2 * a[1][k2], p2 = ax1 * a[2][k1] + ax2 * a[2][k2];
+			const double r = fabs( ax1 ) * bh[k1] + fabs( ax2 ) * bh[k2];
+			if ( fmin( p0, fmin( p1, p2 ) ) > r || fmax( p0, fmax( p1, p2 ) ) < -r )
+				return false;
+		}
+	return true;
+}
+
+// One thread per leaf of the finished tree: finds the leaf's cell by walking down from the root
+// (pre-order: the left sub-tree of node i is [i + 1, right), the right one starts at `right`), moves
+// the records of the triangles that touch the cell to the front of the leaf's range, in order, and
+// lowers the leaf's count.  The records behind them stay where they are, unused.  Nothing is done
+// when the build dropped a reference (see rt_kdtree.h: such a tree keeps the reference's lists).
+__global__ __launch_bounds__( TB ) void k_prune_leaves( rt_hip_kdnode *nodes, uint32_t nNodes, rt_hip_trirec *recs, const GeomInfo *geom, float margin )
+{
+	const uint32_t leaf = blockIdx.x * TB + threadIdx.x;
+	if ( leaf >= nNodes || geom->lostInPlane != 0u )
+		return;
+	const rt_hip_kdnode me = nodes[leaf];
+	if ( ( me.b & 3u ) != 3u || ( me.b >> 2 ) == 0u )
+		return;
+	float lo[3], hi[3];
+	double size = 0.0;
+	for ( int k = 0; k < 3; ++k )
+	{
+		lo[k] = geom->box[k] - geom->box[3 + k];
+		hi[k] = geom->box[k] + geom->box[3 + k];
+		size = fmax( size, fabs( (double) geom->box[k] ) + fabs( (double) geom->box[3 + k] ) );
+	}
+	for ( uint32_t i = 0u; i != leaf; )
+	{
+		const rt_hip_kdnode n = nodes[i];
+		const uint32_t ax = n.b & 3u, right = n.b >> 2;
+		const float sep = __uint_as_float( n.a );
+		if ( leaf < right )
+		{
+			if ( ax == 0u ) hi[0] = sep; else if ( ax == 1u ) hi[1] = sep; else hi[2] = sep;
+			i = i + 1u;
+		}
+		else
+		{
+			if ( ax == 0u ) lo[0] = sep; else if ( ax == 1u ) lo[1] = sep; else lo[2] = sep;
+			i = right;
+		}
+	}
+	const double pad = (double) margin * size;
+	const uint32_t first = me.a, count = me.b >> 2;
+	uint32_t kept = 0u;
+	for ( uint32_t j = 0u; j < count; ++j )
+	{
+		const rt_hip_trirec r = recs[first + j];
+		// (the record holds -v0 and the rounded differences v1 - v0, v2 - v0: v1, v2 are off by half a unit in the last place at most)
+		double q[3][3];
+		q[0][0] = -(double) r.nv0x; q[0][1] = -(double) r.nv0y; q[0][2] = -(double) r.nv0z;
+		q[1][0] = q[0][0] + (double) r.e1x; q[1][1] = q[0][1] + (double) r.e1y; q[1][2] = q[0][2] + (double) r.e1z;
+		q[2][0] = q[0][0] + (double) r.e2x; q[2][1] = q[0][1] + (double) r.e2y; q[2][2] = q[0][2] + (double) r.e2z;
+		if ( tri_touches_cell( q, lo, hi, pad ) )
+		{
+			if ( kept != j )
+				recs[first + kept] = r;
+			++kept;
+		}
+	}
+	if ( kept != count )
+		nodes[leaf].b = ( kept << 2 ) | 3u;
+}
+
 inline unsigned grid_of( size_t n ) { return (unsigned) ( ( n + TB - 1 ) / TB ); }
 
 struct Scratch
@@ -683,7 +795,22 @@ extern "C" void rt_kdtree_device_release( rt_kdtree_device *t )
 extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, int maxDepth, int maxPrims, void *hipStream, rt_kdtree_device *out )
 {
+	rt_kdtree_build_opts o;
+	memset( &o, 0, sizeof( o ) );
+	o.maxDepth = maxDepth;
+	o.maxPrims = maxPrims;
+	return rt_kdtree_build_device_ex( verts, tris, vertexCount, trianglesCount, &o, hipStream, out );
+}
+
+extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
+	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out )
+{
 	g_gpu_build_err[0] = 0;
+	if ( !opts )
+		return 1;
+	if ( opts->sahStop > 0.0f || opts->allAxes )
+		return 2;          // (host builder only)
+	const int maxDepth = opts->maxDepth, maxPrims = opts->maxPrims;
 	if ( !out || ( vertexCount && !verts ) || ( trianglesCount && !tris ) )
 		return 1;
 	if ( trianglesCount >= ( 1ull << 30 ) || maxDepth < 0 || maxDepth > RT_HIP_MAX_TREE_DEPTH || maxPrims < 1 )
@@ -796,7 +923,7 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 				hipcub::CountingInputIterator<uint32_t>( 0u ), F );
 			if ( int rc = exclusive_sum( S.cub, in, S.scan.as<unsigned long long>(), levelRefs, s ) ) return rc;
 			hipLaunchKernelGGL( k_scatter, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, cur, F, levelRefs,
-				S.scan.as<unsigned long long>(), nRefs, nRefNode, S.leafPool.as<uint32_t>(), (uint32_t) leafRefs );
+				S.scan.as<unsigned long long>(), nRefs, nRefNode, S.leafPool.as<uint32_t>(), (uint32_t) leafRefs, &dGeom->lostInPlane );
 		}
 
 		nodesTotal += levelNodes;
@@ -847,6 +974,9 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 	if ( nT )
 		hipLaunchKernelGGL( k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
 			(rt_hip_trishade *) out->shade );
+	if ( opts->pruneLeaves > 0.0f && nRecs )
+		hipLaunchKernelGGL( k_prune_leaves, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (rt_hip_kdnode *) out->nodes, nNodes,
+			(rt_hip_trirec *) out->recs, dGeom, opts->pruneLeaves );
 	hipError_t e = hipGetLastError();
 	if ( e == hipSuccess ) e = hipStreamSynchronize( s );
 	if ( e != hipSuccess )

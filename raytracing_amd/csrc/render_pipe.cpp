@@ -97,7 +97,7 @@ struct rt_pipe_impl
 	std::vector<rt_material> mats;
 	rt_camera cam;
 	int maxDepth = MAX_DEPTH, maxPrims = MAX_PRIMS_IN_NODE, stackSize = STACK_SIZE;
-	int buildThreads = 0, treeCache = 0;
+	int buildThreads = 0, treeCache = 0, pruneLeaves = 0;
 	int gpuBuild = 2;                 // 0 = host builder, 1 = GPU builder, 2 = GPU builder from GPU_BUILD_MIN triangles up
 	int bandH = 16, nParts = 1, part = 0;
 	bool matsDirty = true;
@@ -381,6 +381,12 @@ void rt_render_pipe_set_param( rt_render_pipe *pRp, int key, int value )
 		im->gpuBuild = value;
 		im->haveTree = false;
 		break;
+	case RT_PARAM_PRUNE_LEAVES:
+		if ( rt_hip_set_param( im->hip, key, value ) )
+			die_hip( "rt_render_pipe_set_param" );
+		im->pruneLeaves = value ? 1 : 0;
+		im->haveTree = false;
+		break;
 	case RT_PARAM_OVERLAP:
 	case RT_PARAM_COOP_LIVE:
 	case RT_PARAM_COOP_STACK:
@@ -456,8 +462,13 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 	else if ( !reuse )
 	{
 		rt_kdtree_flat t;
-		int rc = rt_kdtree_build_flat( im->verts.data(), im->tris.data(), im->verts.size(), im->tris.size(),
-			im->maxDepth, im->maxPrims, im->buildThreads, &t );
+		rt_kdtree_build_opts o;
+		memset( &o, 0, sizeof( o ) );
+		o.maxDepth = im->maxDepth;
+		o.maxPrims = im->maxPrims;
+		o.threads = im->buildThreads;
+		o.pruneLeaves = im->pruneLeaves ? RT_PRUNE_LEAVES_MARGIN : 0.0f;
+		int rc = rt_kdtree_build_flat_ex( im->verts.data(), im->tris.data(), im->verts.size(), im->tris.size(), &o, &t );
 		if ( rc )
 		{
 			fprintf( stderr, "rt: kd-tree build failed (%d)\n", rc );

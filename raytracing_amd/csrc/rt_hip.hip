@@ -1962,6 +1962,7 @@ struct rt_hip_ctx
 	int workLights = -1;          // light count the shadow buffer was sized for
 	int maxGrid = 0;
 	int launchWaves = RT_OCC_CAP;                     // RT_PARAM_LAUNCH_WAVES
+	int pruneLeaves = 0;                              // RT_PARAM_PRUNE_LEAVES (trees built by rt_hip_build_tree)
 	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
 	// [frame][(slot * 3 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop; of the
 	// start events only that of the first kernel is recorded (enqueue_frame, frame_times)
@@ -2227,7 +2228,12 @@ int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle 
 	if ( !c ) return fail( "null context" );
 	HIPCHK( hipSetDevice( c->device ) );
 	rt_kdtree_device t;
-	int rc = rt_kdtree_build_device( verts, tris, vertexCount, trianglesCount, maxDepth, maxPrims, c->stream, &t );
+	rt_kdtree_build_opts o;
+	memset( &o, 0, sizeof( o ) );
+	o.maxDepth = maxDepth;
+	o.maxPrims = maxPrims;
+	o.pruneLeaves = c->pruneLeaves ? RT_PRUNE_LEAVES_MARGIN : 0.0f;
+	int rc = rt_kdtree_build_device_ex( verts, tris, vertexCount, trianglesCount, &o, c->stream, &t );
 	if ( rc )
 		return fail( "rt_hip_build_tree: builder returned %d (%s)", rc, rt_kdtree_device_last_error() );
 	if ( rt_hip_adopt_tree( c, &t ) )
@@ -2390,6 +2396,11 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 	{
 		if ( value < 1 || value > 16 ) return fail( "RT_PARAM_LAUNCH_WAVES must be 1..16" );
 		c->launchWaves = value;
+		return 0;
+	}
+	if ( key == RT_PARAM_PRUNE_LEAVES )
+	{
+		c->pruneLeaves = value ? 1 : 0;
 		return 0;
 	}
 	if ( key == RT_PARAM_COOP_STACK )

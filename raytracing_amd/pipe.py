@@ -19,7 +19,7 @@ from ._lib import DeviceTreeStruct, RenderPipeStruct, RtError, Stats, check, lib
 RT_HIP_STATS, RT_HIP_HITIDS, RT_HIP_TIMING = 1, 2, 4
 (RT_PARAM_STACK_SIZE, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE,
  RT_PARAM_BUILD_THREADS, RT_PARAM_TREE_CACHE, RT_PARAM_OVERLAP, RT_PARAM_GPU_BUILD,
- RT_PARAM_COOP_LIVE, RT_PARAM_COOP_STACK, RT_PARAM_LAUNCH_WAVES) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+ RT_PARAM_COOP_LIVE, RT_PARAM_COOP_STACK, RT_PARAM_LAUNCH_WAVES, RT_PARAM_PRUNE_LEAVES) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 kdnode = np.dtype([("a", "<u4"), ("b", "<u4")])
 trirec = np.dtype([("nv0x", "<f4"), ("e1x", "<f4"), ("nv0y", "<f4"), ("e1y", "<f4"),
@@ -56,14 +56,16 @@ class DeviceTree:
         self._s = struct
 
     @classmethod
-    def build(cls, verts, tris, max_depth=10, max_prims=7, stream=None):
+    def build(cls, verts, tris, max_depth=10, max_prims=7, stream=None, prune_leaves=0.0):
+        from ._lib import BuildOpts
         verts = np.ascontiguousarray(verts, T.vertex)
         tris = np.ascontiguousarray(tris, T.triangle)
         s = DeviceTreeStruct()
         L = lib()
         L.rt_kdtree_device_last_error.restype = C.c_char_p
-        rc = L.rt_kdtree_build_device(_p(verts), _p(tris), C.c_uint64(len(verts)), C.c_uint64(len(tris)),
-                                      C.c_int(max_depth), C.c_int(max_prims), C.c_void_p(stream), C.byref(s))
+        o = BuildOpts(max_depth, max_prims, 0, 0.0, 0, prune_leaves)
+        rc = L.rt_kdtree_build_device_ex(_p(verts), _p(tris), C.c_uint64(len(verts)), C.c_uint64(len(tris)),
+                                         C.byref(o), C.c_void_p(stream), C.byref(s))
         if rc:
             raise RtError(f"rt_kdtree_build_device failed with code {rc}: {L.rt_kdtree_device_last_error().decode()}")
         return cls(s)

@@ -72,6 +72,7 @@ int rt_hip_selftest_rcp( rt_hip_ctx *, uint64_t *, uint64_t * ) { return 1; }
 
 // GPU kd builder (kd_build_gpu.hip): not available in this build
 int rt_kdtree_build_device( const rt_vertex *, const rt_triangle *, uint64_t, uint64_t, int, int, void *, rt_kdtree_device * ) { return 1; }
+int rt_kdtree_build_device_ex( const rt_vertex *, const rt_triangle *, uint64_t, uint64_t, const rt_kdtree_build_opts *, void *, rt_kdtree_device * ) { return 1; }
 void rt_kdtree_device_release( rt_kdtree_device * ) {}
 int rt_kdtree_device_download( const rt_kdtree_device *, rt_kdtree_flat * ) { return 1; }
 const char *rt_kdtree_device_last_error( void ) { return "sanitizer stand-in: no device"; }

@@ -135,3 +135,72 @@ def test_headless_app_with_gpu_build_gives_the_same_frames(tmp_path):
         subprocess.run(args + (["--gpu-build"] if mode == "gpu" else ["--host-build"]), cwd=d, check=True, capture_output=True, timeout=120)
         frames[mode] = [open(d / "pngs" / f"{i}.ppm", "rb").read() for i in range(2)]
     assert frames["host"] == frames["gpu"] and frames["host"][0] != frames["host"][1]
+
+
+def _leaf_lists(tree):
+    """{leaf node index: triangle ids in list order} of a flat tree."""
+    nodes, idx = tree.expand()
+    return {int(i): idx[int(nodes["prims"][i]):int(nodes["prims"][i] + nodes["primsCount"][i])].tolist()
+            for i in np.nonzero(nodes["isLast"] != 0)[0]}, nodes
+
+
+@pytest.mark.parametrize("name", ["wavy32", "sphere16k", "soup"])
+def test_device_builder_prunes_leaves_like_the_host_builder(name):
+    """pruneLeaves on the GPU: the finished tree's leaf lists are pruned in place.  Same nodes; every
+    leaf list a sub-sequence of the reference's; compared with the host builder's pruning (exact vertices
+    in double) the lists may differ only in triangles that graze the grown cell."""
+    v, t = random_soup(3000, 21) if name == "soup" else tree_scenes()[name].flatten()
+    depth, prims = 16, 4
+    plain = FlatTree.build(v, t, depth, prims, 4)
+    host = FlatTree.build(v, t, depth, prims, 4, prune_leaves=1e-5)
+    dev = DeviceTree.build(v, t, depth, prims, prune_leaves=1e-5)
+    got = dev.download()
+    assert (dev.n_nodes, dev.n_recs) == (len(plain.nodes), len(plain.recs))       # (pruned in place: the record array keeps its size)
+    lp, pn = _leaf_lists(plain)
+    lh, _ = _leaf_lists(host)
+    lg, gn = _leaf_lists(got)
+    for k in ("isLast", "leftNode", "rightNode", "sep", "axis"):
+        assert np.array_equal(pn[k], gn[k]), k
+    assert np.array_equal(np.where(pn["isLast"] != 0, pn["prims"], 0), np.where(gn["isLast"] != 0, gn["prims"], 0))
+    kept_h = kept_g = differ = 0
+    for i, full in lp.items():
+        it = iter(full)
+        assert all(x in it for x in lg[i]), i                                     # sub-sequence, order kept
+        kept_h += len(lh[i])
+        kept_g += len(lg[i])
+        differ += len(set(lh[i]) ^ set(lg[i]))
+    total = sum(len(x) for x in lp.values())
+    assert kept_g < total and differ <= 1e-3 * total and abs(kept_g - kept_h) <= 1e-3 * total
+    for x in (plain, host, got):
+        x.release()
+    dev.release()
+
+
+def test_device_builder_keeps_the_lists_of_a_tree_that_dropped_triangles():
+    v, t = random_soup(400, seed=7144, extent=2.0, size=0.7)
+    v["pos"]["z"] = 40.0                      # everything in the plane that candidate 16 of the z sweep picks
+    plain = FlatTree.build(v, t, 10, 2, 2)
+    assert len(set(plain.expand()[1].tolist())) < 400
+    dev = DeviceTree.build(v, t, 10, 2, prune_leaves=1e-5)
+    got = dev.download()
+    assert np.array_equal(got.nodes, plain.nodes) and _same_floats(got.recs, plain.recs)
+    dev.release()
+
+
+@pytest.mark.parametrize("gpu_build", [0, 1])
+def test_render_pipe_with_pruned_leaves_draws_the_same_frame(gpu_build):
+    """RT_PARAM_PRUNE_LEAVES through the reference-style API, with either builder."""
+    from raytracing_amd.pipe import RT_PARAM_GPU_BUILD, RT_PARAM_MAX_DEPTH, RT_PARAM_MAX_PRIMS_IN_NODE, RT_PARAM_PRUNE_LEAVES, RenderPipe
+    sc = scenes.config5_frame(11, 320, 180, lon=120, lat=60)
+    frames = []
+    for prune in (0, 1):
+        rp = RenderPipe(sc.w, sc.h)
+        rp.set_param(RT_PARAM_MAX_DEPTH, 20)
+        rp.set_param(RT_PARAM_MAX_PRIMS_IN_NODE, 6)
+        rp.set_param(RT_PARAM_GPU_BUILD, gpu_build)
+        rp.set_param(RT_PARAM_PRUNE_LEAVES, prune)
+        rp.set_camera(sc.camera)
+        rp.add_scene(sc)
+        frames.append(rp.draw().copy())
+        rp.cleanup()
+    assert np.array_equal(frames[0], frames[1]) and frames[0].any()
