@@ -148,7 +148,9 @@ int  rt_hip_set_camera( rt_hip_ctx *c, const rt_camera *cam );
  * a second context on the same GPU, on its own stream, renders frame i + 1 while frame i of the first drains its
  * sparse last passes.  It reads the tree, materials, spheres and lights of `from` (no copies: one working set in
  * the caches); camera, image size, tile and parameters stay per context.  `from` must outlive every frame of `c`,
- * and uploads into `from` must not run beside frames of `c`. */
+ * and uploads into `from` must not run beside frames of `c`.  After ANY upload into `from` (tree, materials, spheres,
+ * lights, an adopted tree) and after its destruction the copied device pointers may dangle: rt_hip_render on `c` then
+ * returns an error until rt_hip_share_scene is called again. */
 int  rt_hip_share_scene( rt_hip_ctx *c, const rt_hip_ctx *from );
 
 /* full image size; allocates the per-pixel work buffers */
@@ -183,8 +185,13 @@ int  rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags );
  * rt_hip_local_rows() rt_argb) is required, flags must be 0, tree / materials /
  * spheres / lights must have been uploaded (empty tables included), passes run
  * in order on the context's stream.  Every call on a GPU uses that GPU's one
- * array: calls that overlap in time on one GPU (two contexts, two streams) race.
- * Same pixels as rt_hip_render.
+ * array, so the entry point is SINGLE-FLIGHT PER GPU: frames enqueued on one
+ * stream follow each other; a call on another stream (another context, or after
+ * rt_hip_set_stream) while the previous frame has not completed is refused
+ * with an error - synchronise first.  (Not checked under stream capture:
+ * whoever replays captured frames keeps them apart.)  rt_hip_sync reports a
+ * frame whose lists ran out of room, as for rt_hip_render.  Same pixels as
+ * rt_hip_render.
  */
 #define RT_HIP_NOALLOC_MAX_PIXELS 65536
 #define RT_HIP_NOALLOC_MAX_SLOTS  6

@@ -66,22 +66,48 @@ def build():
     subprocess.run(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")], check=True)
 
 
+def _hip_soname(path):
+    """The versioned libamdhip64 name an ELF file carries: for librt_amd.so the runtime it was linked against
+    (DT_NEEDED), for a copy of the runtime its own DT_SONAME."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            m = re.search(rb"libamdhip64\.so\.\d+", f.read())
+        return m.group(0).decode() if m else None
+    except OSError:
+        return None
+
+
 def _share_hip_runtime_with_torch():
     """PyTorch-ROCm wheels carry their own libamdhip64.so.  Two HIP runtimes in one
-    process do not work: the one that comes second finds no device.  When torch
-    is installed its copy is therefore mapped first (without importing torch), and
-    librt_amd.so's own dependency on libamdhip64 binds to it by soname, whichever
-    of the two the application happens to use first."""
+    process do not work: the one that comes second finds no device.  A process that
+    uses torch as well (torch already imported, or RT_AMD_SHARE_TORCH_HIP=1 for one
+    that imports it later) therefore maps torch's copy first, so that librt_amd.so's
+    own dependency binds to it by soname.  Only a copy with the soname the library
+    was linked against is taken; a process that never uses torch gets the system
+    runtime (RT_AMD_SHARE_TORCH_HIP=0 forces that)."""
     import glob
     import importlib.util
+    import sys
+    import warnings
+    want = os.environ.get("RT_AMD_SHARE_TORCH_HIP")
+    if want == "0" or (want != "1" and "torch" not in sys.modules):
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if not spec or not spec.submodule_search_locations:
         return
+    soname = _hip_soname(SO)
     for d in spec.submodule_search_locations:
-        for so in sorted(glob.glob(os.path.join(d, "lib", "libamdhip64.so*"))):
+        found = sorted(glob.glob(os.path.join(d, "lib", "libamdhip64.so*")))
+        names = {so: _hip_soname(so) for so in found}
+        match = [so for so in found if soname and names[so] == soname]
+        if found and not match:
+            warnings.warn(f"torch ships {sorted(set(names.values()), key=str)} but {os.path.basename(SO)} was linked against "
+                          f"{soname}: not sharing torch's HIP runtime (two runtimes in one process: the second finds no device)")
+        for so in match:
             try:
                 C.CDLL(so, mode=C.RTLD_GLOBAL)
                 return

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "rt_hip.h"
 
@@ -57,9 +58,12 @@ struct Rccl
 	const char *( *GetErrorString )( ncclResult_t ) = nullptr;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mu;
 
 int load_rccl()
 {
+	// (several host threads may open communicators at once)
+	std::lock_guard<std::mutex> lock( g_rccl_mu );
 	if ( g_rccl.so )
 		return 0;
 	const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
@@ -89,6 +93,10 @@ int load_rccl()
 
 #define NCCLCHK( x ) do { ncclResult_t r_ = ( x ); if ( r_ != ncclSuccess ) \
 	return fail( "%s failed: %s", #x, g_rccl.GetErrorString( r_ ) ); } while ( 0 )
+// inside an open group: the group is closed (whatever that returns) before the error is reported,
+// so the thread's later RCCL calls do not land in a group nobody ends
+#define NCCLCHK_IN_GROUP( x ) do { ncclResult_t r_ = ( x ); if ( r_ != ncclSuccess ) { \
+	(void) g_rccl.GroupEnd(); return fail( "%s failed: %s", #x, g_rccl.GetErrorString( r_ ) ); } } while ( 0 )
 
 // out[y][x] = stage[band % nParts][(band / nParts) * bandH + y % bandH][x], band = y / bandH; one 4-byte pixel per thread
 __global__ __launch_bounds__( 256 ) void k_deinterleave( const uint32_t *stage, uint32_t *out, int w, int h, int bandH, int nParts, int padRows )
@@ -115,6 +123,8 @@ struct rt_hip_comm
 	ncclComm_t comm = nullptr;
 	void *stage = nullptr;          // destination rank: nRanks padded shares
 	size_t stageBytes = 0;
+	hipStream_t lastStream = nullptr;   // stream of the gather enqueued last (it may still be writing `stage`)
+	bool used = false;
 };
 
 extern "C" {
@@ -196,12 +206,16 @@ int rt_hip_gather_frame( rt_hip_comm *m, const void *d_local, void *d_frame, int
 	{
 		// (first frame, or a larger image than before: the only allocation of the exchange)
 		HIPCHK( hipStreamSynchronize( s ) );
+		// a gather enqueued earlier on another stream may still be filling the old stage
+		if ( m->used && m->lastStream != s ) HIPCHK( hipStreamSynchronize( m->lastStream ) );
 		if ( m->stage ) HIPCHK( hipFree( m->stage ) );
 		m->stage = nullptr;
 		m->stageBytes = 0;
 		HIPCHK( hipMalloc( &m->stage, slab * m->nRanks ) );
 		m->stageBytes = slab * m->nRanks;
 	}
+	m->lastStream = s;
+	m->used = true;
 	if ( m->rank == dst )
 	{
 		// own share: a device copy; the others: one receive each, all inside one group
@@ -211,13 +225,13 @@ int rt_hip_gather_frame( rt_hip_comm *m, const void *d_local, void *d_frame, int
 			NCCLCHK( g_rccl.GroupStart() );
 			for ( int r = 0; r < m->nRanks; ++r )
 				if ( r != dst )
-					NCCLCHK( g_rccl.Recv( (char *) m->stage + slab * r, slab, ncclUint8, r, m->comm, s ) );
+					NCCLCHK_IN_GROUP( g_rccl.Recv( (char *) m->stage + slab * r, slab, ncclUint8, r, m->comm, s ) );
 			NCCLCHK( g_rccl.GroupEnd() );
 		}
 		return rt_hip_deinterleave( m->stage, d_frame, w, h, bandH, m->nRanks, s );
 	}
 	NCCLCHK( g_rccl.GroupStart() );
-	NCCLCHK( g_rccl.Send( d_local, slab, ncclUint8, dst, m->comm, s ) );
+	NCCLCHK_IN_GROUP( g_rccl.Send( d_local, slab, ncclUint8, dst, m->comm, s ) );
 	NCCLCHK( g_rccl.GroupEnd() );
 	return 0;
 }

@@ -185,9 +185,13 @@ bool tri_touches_cell( const rt_vector3 &q0, const rt_vector3 &q1, const rt_vect
 	}
 	for ( int k = 0; k < 3; ++k )
 	{
+		// a coordinate that is not a number: keep the triangle (std::min / std::max would
+		// drop a NaN that is not their first argument; the GPU builder tests all three too)
+		if ( a[0][k] != a[0][k] || a[1][k] != a[1][k] || a[2][k] != a[2][k] )
+			return true;
 		const double mn = std::min( a[0][k], std::min( a[1][k], a[2][k] ) ), mx = std::max( a[0][k], std::max( a[1][k], a[2][k] ) );
 		if ( !( mn <= bh[k] && mx >= -bh[k] ) )
-			return mn != mn || mx != mx;                  // apart, unless a coordinate is not a number: keep
+			return false;
 	}
 	double e[3][3];
 	for ( int k = 0; k < 3; ++k )

@@ -37,6 +37,7 @@
 // with the CPU restatement used by the tests.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -191,6 +192,7 @@ struct Work
 	uint32_t coopCap;                     // stack entries per ray the cooperative walk may use (<= RT_LDS_STACK; less only in tests)
 	uint32_t npix, tilesX, nChunks0, spillStride;
 	uint32_t cap;                         // entries per ray list / hit list (npix + room for reservation holes)
+	uint32_t exactAppends;                // 1 = lists are appended without block reservations (no holes: a list of cap = npix entries cannot overflow)
 };
 
 struct Ray { f3 src, dest, inv; };
@@ -277,8 +279,10 @@ DEVI uint32_t list_append( uint32_t *counter, Resv &r, bool want, uint32_t block
 	return idx;
 }
 // reservation size for the output of a pass over `count` input entries
-DEVI uint32_t resv_block( uint32_t count )
+DEVI uint32_t resv_block( const Work &W, uint32_t count )
 {
+	if ( W.exactAppends )
+		return 0u;
 	return count >= gridDim.x * ( RT_BLOCK / 64u ) * 64u * 4u ? RT_RESV_BLOCK : 0u;
 }
 
@@ -1599,7 +1603,7 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 	uint32_t first;
 	Grab grab = { 0u };
 	ClosestOut out = {};
-	out.block = resv_block( count );
+	out.block = resv_block( W, count );
 	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_DYN, shift ) )
 	{
 #ifdef RT_PROFILE_CHUNKS
@@ -1937,6 +1941,20 @@ struct DevBuf
 	size_t cap = 0;
 };
 
+// What a context that lends its scene (rt_hip_share_scene) and its borrowers have in common:
+// a generation number that every upload into the lender - and its destruction - advances, so
+// that a borrower notices that the device pointers it copied may no longer be the lender's.
+struct SceneTag
+{
+	std::atomic<uint64_t> gen{ 1 };
+	std::atomic<int> refs{ 1 };
+};
+static void scene_tag_release( SceneTag *t )
+{
+	if ( t && t->refs.fetch_sub( 1 ) == 1 )
+		delete t;
+}
+
 struct rt_hip_ctx
 {
 	int device = 0;
@@ -1971,7 +1989,22 @@ struct rt_hip_ctx
 	bool haveEvents = false;
 	int timedSlots = 0, timedFrames = 0;
 	uint32_t validPixels = 0;
+	Counters *lastCtr = nullptr;  // counters of the frame enqueued last (either entry point): where its overflow flag is read
+	uint32_t lastCap = 0;
+	SceneTag *tag = nullptr;      // generation of the scene this context holds (and may lend)
+	SceneTag *lender = nullptr;   // rt_hip_share_scene: the lender's tag and its generation at that time
+	uint64_t lenderGen = 0;
 };
+
+// every change of a context's scene buffers (upload, adoption of a tree)
+static void scene_changed( rt_hip_ctx *c ) { if ( c->tag ) c->tag->gen.fetch_add( 1 ); }
+// a borrower may only render while the lender's scene is the one it copied the pointers of
+static int lender_unchanged( const rt_hip_ctx *c, const char *who )
+{
+	if ( c->lender && c->lender->gen.load() != c->lenderGen )
+		return fail( "%s: the context whose scene this one shares has uploaded a scene again or was destroyed; call rt_hip_share_scene again", who );
+	return 0;
+}
 
 const char *rt_hip_last_error( void ) { return g_err; }
 
@@ -2031,10 +2064,12 @@ rt_hip_ctx *rt_hip_create( int device )
 	}
 	rt_hip_ctx *c = new rt_hip_ctx();
 	c->device = device;
+	c->tag = new SceneTag();
 	hipDeviceProp_t prop;
 	if ( hipGetDeviceProperties( &prop, device ) != hipSuccess || hipStreamCreate( &c->own ) != hipSuccess )
 	{
 		fail( "rt_hip_create: device query / stream creation failed" );
+		scene_tag_release( c->tag );
 		delete c;
 		return nullptr;
 	}
@@ -2120,6 +2155,9 @@ void rt_hip_destroy( rt_hip_ctx *c )
 	if ( c->haveEvents )
 		for ( auto &f : c->ev ) for ( auto &e : f ) (void) hipEventDestroy( e );
 	if ( c->own ) (void) hipStreamDestroy( c->own );
+	if ( c->tag ) c->tag->gen.store( ~0ull );        // borrowers: the scene is gone
+	scene_tag_release( c->tag );
+	scene_tag_release( c->lender );
 	delete c;
 }
 
@@ -2176,6 +2214,7 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 		if ( shade[i].mat > maxMat ) maxMat = shade[i].mat;
 	c->maxMatTree = maxMat;
 	HIPCHK( hipSetDevice( c->device ) );
+	scene_changed( c );
 	if ( upload( c, c->nodes, nodes, nNodes * sizeof( rt_hip_kdnode ) ) ) return 1;
 	// one spare record: the leaf loop loads one record ahead
 	if ( ensure( c, c->recs, ( nRecs + 1 ) * sizeof( rt_hip_trirec ) ) ) return 1;
@@ -2199,8 +2238,10 @@ int rt_hip_adopt_tree( rt_hip_ctx *c, rt_kdtree_device *t )
 	if ( t->nNodes >= ( 1ull << 30 ) || t->nRecs >= ( 1ull << 30 ) || t->nTris >= ( 1ull << 31 ) )
 		return fail( "rt_hip_adopt_tree: tree too large for 32-bit node links" );
 	HIPCHK( hipSetDevice( c->device ) );
-	// frames that still read the old tree must be done before it is freed
+	// frames that still read the old tree must be done before it is freed (hipFree also waits for the
+	// device, frames of borrowers included; borrowers must share again before their next frame)
 	HIPCHK( hipStreamSynchronize( c->stream ) );
+	scene_changed( c );
 	DevBuf *dst[3] = { &c->nodes, &c->recs, &c->shade };
 	void *src[3] = { t->nodes, t->recs, t->shade };
 	const size_t bytes[3] = { t->nNodes * sizeof( rt_hip_kdnode ), ( t->nRecs + 1 ) * sizeof( rt_hip_trirec ),
@@ -2266,6 +2307,11 @@ int rt_hip_share_scene( rt_hip_ctx *c, const rt_hip_ctx *from )
 	memcpy( c->S.bbE, from->S.bbE, sizeof( c->S.bbE ) );
 	c->nNodes = from->nNodes; c->nRecs = from->nRecs; c->nTris = from->nTris; c->nMats = from->nMats;
 	c->maxMatTree = from->maxMatTree; c->maxMatSphere = from->maxMatSphere; c->treeDepth = from->treeDepth;
+	scene_tag_release( c->lender );
+	c->lender = from->tag;
+	c->lender->refs.fetch_add( 1 );
+	c->lenderGen = c->lender->gen.load();
+	scene_changed( c );                              // (whoever borrowed from c)
 	return 0;
 }
 
@@ -2273,6 +2319,7 @@ int rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n )
 {
 	if ( !c || ( n && !m ) ) return fail( "rt_hip_upload_materials: bad arguments" );
 	HIPCHK( hipSetDevice( c->device ) );
+	scene_changed( c );
 	if ( upload( c, c->mats, m, n * sizeof( rt_material ) ) ) return 1;
 	c->nMats = n;
 	c->S.alphaMonotone = 1;
@@ -2297,6 +2344,7 @@ int rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n )
 		g[4 * i] = s[i].pos.x; g[4 * i + 1] = s[i].pos.y; g[4 * i + 2] = s[i].pos.z; g[4 * i + 3] = s[i].rad;
 		mi[i] = (uint32_t) s[i].mat;
 	}
+	scene_changed( c );
 	if ( upload( c, c->spheres, g.data(), 16 * n ) ) return 1;
 	if ( upload( c, c->sphereMat, mi.data(), 4 * n ) ) return 1;
 	c->S.spheres = (const float4 *) c->spheres.p;
@@ -2317,6 +2365,7 @@ int rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n )
 		p[4] = l[i].pos.x; p[5] = l[i].pos.y; p[6] = l[i].pos.z;
 		p[8] = l[i].rad;
 	}
+	scene_changed( c );
 	if ( upload( c, c->lights, g.data(), 48 * n ) ) return 1;
 	c->S.lights = (const float4 *) c->lights.p;
 	c->S.nLights = (int) n;
@@ -2495,6 +2544,7 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 {
 	if ( !c ) return fail( "null context" );
+	if ( lender_unchanged( c, "rt_hip_render" ) ) return 1;
 	if ( !c->S.nodes ) return fail( "rt_hip_render: no tree uploaded" );
 	if ( !c->S.mats ) return fail( "rt_hip_render: no materials uploaded" );
 	// a material slot beyond the uploaded table would be an out-of-bounds read on the GPU
@@ -2540,6 +2590,8 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 	// end events of k_closest<k> and k_light<k> are the very events the fork and the join need, so a
 	// timed frame puts 8 markers more into the streams than an untimed one, not 34.
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
+	c->lastCtr = W.ctr;
+	c->lastCap = W.cap;
 	HIPCHK( hipMemsetAsync( W.ctr, 0, sizeof( Counters ), s ) );
 	if ( W.npix == 0 )
 		return 0;
@@ -2605,12 +2657,16 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 	return 0;
 }
 
+static int check_overflow( rt_hip_ctx *c );
+
+// Waits for everything enqueued on the context's stream and reports a frame whose work lists ran out of
+// room (either entry point; the flag lives in the counters of the frame enqueued last).
 int rt_hip_sync( rt_hip_ctx *c )
 {
 	if ( !c ) return fail( "null context" );
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
-	return 0;
+	return check_overflow( c );
 }
 
 // ---------------------------------------------------------------------------
@@ -2622,18 +2678,22 @@ int rt_hip_sync( rt_hip_ctx *c )
 // its own copy of the array, at its own address, until the process ends; the
 // address is looked up once per device (rt_hip_create) and only that pointer is
 // ever handed to kernels or memsets.  All calls on one GPU share the array:
-// frames that overlap in time on one GPU race.  The counters are cleared at the
-// start of every frame; nothing else needs to start at zero (every list is
-// bounded by its own counter, every per-pixel record is written before it is
-// read).
+// frames that overlap in time on one GPU race, so the entry point is
+// single-flight per GPU: a call on another stream than the previous call's is
+// refused while that previous frame has not completed (noalloc_flight).  The
+// counters are cleared at the start of every frame; nothing else needs to start
+// at zero (every list is bounded by its own counter, every per-pixel record is
+// written before it is read).
 // ---------------------------------------------------------------------------
-#define RT_NOALLOC_GRID ( 32768 / RT_BLOCK )      // workgroups per persistent launch: 512 waves (sizes the stack-overflow strip)
+#define RT_NOALLOC_GRID ( 32768 / RT_BLOCK )      // most workgroups per persistent launch: 512 waves (sizes the stack-overflow strip)
 
 constexpr size_t noalloc_align( size_t x ) { return ( x + 255 ) & ~(size_t) 255; }
 struct NoallocLayout
 {
-	// entries per list: no launch here uses block reservations (they start at
-	// 512 waves x 256 = 131072 entries per list), so a list holds at most one entry per pixel
+	// entries per list: the frames of this entry point append without block
+	// reservations (Work::exactAppends - whatever the grid a launch ends up with,
+	// and whatever the padded length of the slot-0 list of a narrow image), so a
+	// list has no holes and holds at most one entry per pixel
 	static constexpr size_t cap = RT_HIP_NOALLOC_MAX_PIXELS + 64;
 	static constexpr size_t npix = RT_HIP_NOALLOC_MAX_PIXELS;
 	static constexpr size_t slots = RT_HIP_NOALLOC_MAX_SLOTS, lights = RT_HIP_NOALLOC_MAX_LIGHTS;
@@ -2651,7 +2711,6 @@ struct NoallocLayout
 	static constexpr size_t total = oSpill + noalloc_align( sizeof( uint2 ) * (size_t) RT_NOALLOC_GRID * RT_BLOCK * RT_SPILL_CAP );
 };
 static_assert( RT_HIP_NOALLOC_MAX_SLOTS >= 2 && RT_HIP_NOALLOC_MAX_SLOTS <= RT_MAX_SLOTS, "slot limit of the allocation-free entry point" );
-static_assert( NoallocLayout::cap < (size_t) RT_NOALLOC_GRID * ( RT_BLOCK / 64 ) * RT_RESV_BLOCK, "lists must stay below the length at which reservations (holes) begin" );
 static_assert( NoallocLayout::total <= RT_HIP_NOALLOC_BYTES, "RT_HIP_NOALLOC_BYTES in rt_hip.h must cover the layout" );
 
 static __device__ __align__( 256 ) unsigned char scratch[RT_HIP_NOALLOC_BYTES];
@@ -2659,6 +2718,10 @@ static __device__ __align__( 256 ) unsigned char scratch[RT_HIP_NOALLOC_BYTES];
 // device address of `scratch` on each GPU (the array's name is only a handle on the host)
 #define RT_MAX_DEVICES 64
 static unsigned char *g_scratch_ptr[RT_MAX_DEVICES] = {};
+// the allocation-free frame enqueued last on each GPU: its stream, and an event behind it
+// (created with the scratch look-up, i.e. at set-up, not by the entry point)
+struct NoallocFlight { hipEvent_t done = nullptr; hipStream_t stream = nullptr; bool pending = false; };
+static NoallocFlight g_flight[RT_MAX_DEVICES];
 
 static int scratch_lookup( int device )
 {
@@ -2669,7 +2732,30 @@ static int scratch_lookup( int device )
 	HIPCHK( hipSetDevice( device ) );
 	HIPCHK( hipGetSymbolAddress( (void **) &p, HIP_SYMBOL( scratch ) ) );
 	if ( !p ) return fail( "hipGetSymbolAddress returned a null address for the scratch array" );
+	HIPCHK( hipEventCreateWithFlags( &g_flight[device].done, hipEventDisableTiming ) );
 	g_scratch_ptr[device] = p;
+	return 0;
+}
+
+// Single flight per GPU: every allocation-free frame on a GPU uses that GPU's one work area.  Frames
+// enqueued on ONE stream follow each other; a frame on another stream would run beside the previous
+// one and both would write the same lists, so it is refused until the previous frame has completed.
+// (Under stream capture nothing is enqueued yet and events cannot be queried: the caller who replays
+// captured frames keeps them apart himself.)
+static int noalloc_flight_check( int device, hipStream_t s, bool &capturing )
+{
+	NoallocFlight &f = g_flight[device];
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	HIPCHK( hipStreamIsCapturing( s, &cs ) );
+	capturing = cs != hipStreamCaptureStatusNone;
+	if ( capturing || !f.pending || f.stream == s )
+		return 0;
+	const hipError_t q = hipEventQuery( f.done );
+	if ( q == hipErrorNotReady )
+		return fail( "rt_hip_render_noalloc: the previous allocation-free frame on GPU %d, enqueued on another stream, has not completed; "
+			"the entry point is single-flight per GPU (one shared work area): synchronise that stream first, or enqueue on the same stream", device );
+	HIPCHK( q );
+	f.pending = false;
 	return 0;
 }
 
@@ -2678,6 +2764,7 @@ int rt_hip_render_noalloc( rt_hip_ctx *c, void *d_out, unsigned flags )
 	if ( !c ) return fail( "null context" );
 	if ( !d_out ) return fail( "rt_hip_render_noalloc: an output buffer is required" );
 	if ( flags != 0u ) return fail( "rt_hip_render_noalloc: flags are not supported (counting, hit ids and timing use buffers of rt_hip_render)" );
+	if ( lender_unchanged( c, "rt_hip_render_noalloc" ) ) return 1;
 	if ( !c->S.nodes || !c->S.mats || !c->S.spheres || !c->S.lights )
 		return fail( "rt_hip_render_noalloc: upload tree, materials, spheres and lights first (empty tables included)" );
 	if ( ( c->nRecs && c->maxMatTree >= c->nMats ) || ( c->S.nSpheres && c->maxMatSphere >= c->nMats ) )
@@ -2694,6 +2781,8 @@ int rt_hip_render_noalloc( rt_hip_ctx *c, void *d_out, unsigned flags )
 	HIPCHK( hipSetDevice( c->device ) );
 	unsigned char *base = g_scratch_ptr[c->device];
 	if ( !base ) return fail( "rt_hip_render_noalloc: no scratch address for device %d", c->device );
+	bool capturing = false;
+	if ( noalloc_flight_check( c->device, c->stream, capturing ) ) return 1;
 
 	typedef NoallocLayout L;
 	Work W;
@@ -2718,18 +2807,29 @@ int rt_hip_render_noalloc( rt_hip_ctx *c, void *d_out, unsigned flags )
 	W.tilesX = (uint32_t) ( ( S.w + 7 ) / 8 );
 	W.nChunks0 = W.tilesX * (uint32_t) ( ( S.localH + 7 ) / 8 );
 	W.spillStride = (uint32_t) RT_NOALLOC_GRID * RT_BLOCK;
+	W.exactAppends = 1u;
 	// one stream, passes in order: one stack-overflow strip is enough
-	return enqueue_frame( c, W, (rt_argb *) d_out, 0u, false, RT_NOALLOC_GRID );
+	if ( enqueue_frame( c, W, (rt_argb *) d_out, 0u, false, RT_NOALLOC_GRID ) ) return 1;
+	if ( !capturing )
+	{
+		NoallocFlight &f = g_flight[c->device];
+		HIPCHK( hipEventRecord( f.done, c->stream ) );
+		f.stream = c->stream;
+		f.pending = true;
+	}
+	return 0;
 }
 
 // after a synchronisation: did any list append of the last frame run out of room?
 static int check_overflow( rt_hip_ctx *c )
 {
+	if ( !c->lastCtr )
+		return 0;
 	uint32_t ov = 0;
-	HIPCHK( hipMemcpyAsync( &ov, (char *) c->ctr.p + offsetof( Counters, overflow ), sizeof( ov ), hipMemcpyDeviceToHost, c->stream ) );
+	HIPCHK( hipMemcpyAsync( &ov, (char *) c->lastCtr + offsetof( Counters, overflow ), sizeof( ov ), hipMemcpyDeviceToHost, c->stream ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	if ( ov )
-		return fail( "the last frame overflowed work list %u (1 hits, 2 rays; capacity %u entries): the image is incomplete", ov, c->W.cap );
+		return fail( "the last frame overflowed work list %u (1 hits, 2 rays; capacity %u entries): the image is incomplete", ov, c->lastCap );
 	return 0;
 }
 

@@ -176,6 +176,31 @@ def test_device_builder_prunes_leaves_like_the_host_builder(name):
     dev.release()
 
 
+@pytest.mark.parametrize("corner", [0, 1, 2])
+def test_both_builders_keep_a_triangle_with_a_nan_vertex_when_pruning(corner):
+    """A NaN coordinate in any vertex keeps the triangle in every leaf that lists it, on the host and on the GPU."""
+    v, t = random_soup(1200, 77)
+    bad = np.arange(5, 1200, 97)
+    v["pos"]["xyz"[corner]][3 * bad + corner] = np.nan
+    plain = FlatTree.build(v, t, 14, 4, 2)
+    host = FlatTree.build(v, t, 14, 4, 2, prune_leaves=1e-5)
+    dev = DeviceTree.build(v, t, 14, 4, prune_leaves=1e-5)
+    got = dev.download()
+    lp, _ = _leaf_lists(plain)
+    lh, _ = _leaf_lists(host)
+    lg, _ = _leaf_lists(got)
+    if corner:          # (a NaN in vertex 0 makes the reference's partition drop the triangle: neither builder prunes then)
+        assert sum(len(x) for x in lg.values()) < sum(len(x) for x in lp.values())
+    badset = set(bad.tolist())
+    for i, full in lp.items():
+        want = [x for x in full if x in badset]
+        assert [x for x in lh[i] if x in badset] == want, i
+        assert [x for x in lg[i] if x in badset] == want, i
+    for x in (plain, host, got):
+        x.release()
+    dev.release()
+
+
 def test_device_builder_keeps_the_lists_of_a_tree_that_dropped_triangles():
     v, t = random_soup(400, seed=7144, extent=2.0, size=0.7)
     v["pos"]["z"] = 40.0                      # everything in the plane that candidate 16 of the z sweep picks

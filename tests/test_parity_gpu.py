@@ -1004,8 +1004,24 @@ def test_frames_in_flight_on_contexts_that_share_one_scene():
         r.sync()
         assert np.array_equal(o.cpu().numpy(), img)          # (a frame given a destination is written there only)
         assert np.array_equal(r.read_hit_ids(), ids)
+    # an upload into the lender may move its buffers: the borrower has to share again before its next frame
+    first.upload_materials(sc.material_table())
+    with pytest.raises(Exception, match="rt_hip_share_scene again"):
+        second.render(0, d_out=outs[1].data_ptr())
+    second.share_scene(first, sc)                       # (sc.camera is the second camera)
+    second.render(RT_HIP_HITIDS, d_out=outs[1].data_ptr())
+    second.sync()
+    assert np.array_equal(outs[1].cpu().numpy(), alone[1][0])
+    # and so does the lender's destruction
+    third = HipRenderer(0)
+    third.share_scene(second, sc)                       # a borrower lends what it borrowed
+    third.render(0)
+    third.sync()
     # the borrower goes first; the owner's scene is still whole afterwards
     second.close()
+    with pytest.raises(Exception, match="rt_hip_share_scene again"):
+        third.render(0)
+    third.close()
     first.render(RT_HIP_HITIDS)
     assert np.array_equal(first.read_frame(), alone[0][0])
     first.close()

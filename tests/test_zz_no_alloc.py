@@ -11,7 +11,7 @@ import pytest
 from raytracing_amd import scenes
 from raytracing_amd import types as T
 from raytracing_amd._lib import RtError, check, lib
-from raytracing_amd.pipe import RT_PARAM_STACK_SIZE, FlatTree, HipRenderer
+from raytracing_amd.pipe import RT_PARAM_LAUNCH_WAVES, RT_PARAM_STACK_SIZE, FlatTree, HipRenderer
 
 pytestmark = pytest.mark.gpu
 
@@ -99,4 +99,63 @@ def test_noalloc_frame_in_a_graph_on_a_context_that_never_rendered():
             assert np.array_equal(out.cpu().numpy(), want)
         del g
         r.close()
+    tree.release()
+
+
+@pytest.mark.parametrize("w,h,waves", [(256, 256, 1), (4, 16384, 16), (256, 256, 16)])
+def test_noalloc_lists_have_no_reservation_holes_whatever_the_grid(w, h, waves):
+    """The work area holds one list entry per pixel.  Block reservations (which leave holes) begin when a list is
+    long against the grid of its launch: a grid of one wave per CU, or the padded slot-0 list of an image 4
+    pixels wide (one 8x8 tile per 8 rows: twice as many entries as pixels), would reach that length within the
+    pixel limit.  The allocation-free frame appends exactly, so it is still the frame of rt_hip_render, and
+    rt_hip_sync reports no overflow."""
+    import torch
+    sc = _scene(w, h)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 18, 5)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        r = HipRenderer(0, stream=s.cuda_stream)
+        r.load_scene(sc, tree)
+        r.set_param(RT_PARAM_LAUNCH_WAVES, waves)
+        a = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        b = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+        r.render(0, d_out=a.data_ptr())
+        r.sync()
+        _noalloc(r, b)
+        r.sync()                                          # (raises if a list of the frame overflowed)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert a.any() and np.array_equal(a, b)
+        r.close()
+    tree.release()
+
+
+def test_noalloc_is_single_flight_per_gpu():
+    """Every allocation-free frame on a GPU uses that GPU's one work area: a second frame on ANOTHER stream is
+    refused while the first has not completed; on the same stream it simply follows."""
+    import torch
+    sc = _scene(160, 96)
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 14, 7)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = HipRenderer(0, stream=s1.cuda_stream)
+    a.load_scene(sc, tree)
+    b = HipRenderer(0, stream=s2.cuda_stream)
+    b.share_scene(a, sc)
+    want = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda")
+    oa, ob = torch.zeros_like(want), torch.zeros_like(want)
+    a.render(0, d_out=want.data_ptr())
+    a.sync()
+    with torch.cuda.stream(s1):
+        torch.cuda._sleep(400_000_000)                    # the frame below cannot have completed when b asks
+    _noalloc(a, oa)
+    _noalloc(a, oa)                                       # same stream: follows
+    with pytest.raises(RtError, match="single-flight"):
+        _noalloc(b, ob)
+    a.sync()
+    _noalloc(b, ob)                                       # the first frame has completed: accepted
+    b.sync()
+    assert np.array_equal(oa.cpu().numpy(), want.cpu().numpy()) and np.array_equal(ob.cpu().numpy(), want.cpu().numpy())
+    b.close()
+    a.close()
     tree.release()
