@@ -28,9 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# A frame runs on three streams (closest-hit chain + two auxiliary ones) and three frames are in
+# A frame runs on three streams (closest-hit chain + two auxiliary ones) and four frames are in
 # flight; with the null stream (the kd-tree builder's) and the collective library's streams a rank
-# uses ten to fourteen.  The runtime's default of four hardware queues per process folds several
+# uses thirteen to seventeen.  The runtime's default of four hardware queues per process folds several
 # streams into one queue, which serialises what is meant to overlap: measured, a frame of two in
 # flight costs 7.2 ms at 8 queues (one stream too few) and 6.8 ms from 10 on.  Must be set before
 # the HIP runtime starts (the machine exports 4, hence an assignment).
@@ -61,6 +61,8 @@ TREE_DEPTH, TREE_LEAF = 26, 12
 # quarter fewer triangle tests per ray.  --prune-leaves 0 renders the reference's leaf lists.
 PRUNE_LEAVES = 1e-5
 ORBIT_FRAMES = 240
+IN_FLIGHT = 4                         # frames in flight (contexts that share the resident scene)
+PROFILE_TAG = "profiles/r03"          # the committed profiler summaries the line refers to
 
 WORKLOADS = {
     "config3": dict(make=scenes.config3, text="1M-triangle displaced sphere + floor, 3840x2160, "
@@ -92,12 +94,12 @@ def union_length(spans):
 
 def committed_counters(args, kernel, world):
     """What the committed rocprofv3 counter passes of this same frame say about
-    `kernel` (profiles/r02_counters.json, written by tools/refresh_profiles.py:
+    `kernel` (profiles/r03_counters.json, written by tools/refresh_profiles.py:
     fabric traffic per launch with the gfx950 FETCH_SIZE correction, and the
     ratios that show what binds the kernel), or None when that file does not
     cover this configuration.  Counters cannot be read live."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
+        t = json.load(open(os.path.join(ROOT, PROFILE_TAG + "_counters.json")))
     except (OSError, ValueError):
         return None
     key = (f"{args.workload}/depth{args.depth}/leaf{args.leaf}{'/pruned' if args.prune_leaves > 0 else ''}/gpus{world}/"
@@ -141,6 +143,84 @@ def cpu_baseline(sc, v, t, tree, seconds):
                                  "sample": shallow_txt}}
 
 
+def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, plain=None):
+    """A short run of another workload for the default line's `other_configs`: frames in flight as in the
+    timed region of the main workload, as many warm-up steps, `steps` timed steps, every slot's last frame compared with the
+    same camera's frame rendered alone from the reference's leaf lists.  tree / plain: trees to reuse (same geometry)."""
+    wl = WORKLOADS[name]
+    sequence = name == "config5"
+    sc = wl["make"]()
+    v, t = sc.flatten()
+    own = tree is None
+    if own:
+        tree = FlatTree.build(v, t, depth, leaf, prune_leaves=prune)
+        plain = FlatTree.build(v, t, depth, leaf) if prune > 0 else None
+    slots = []
+    for k in range(IN_FLIGHT):
+        st = torch.cuda.Stream()
+        r = HipRenderer(local_dev, stream=st.cuda_stream)
+        if k == 0:
+            r.load_scene(sc, tree)
+        else:
+            r.share_scene(slots[0][0], sc)
+        r.set_param(RT_PARAM_LAUNCH_WAVES, 8)
+        slots.append((r, torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device=dev)))
+    checker = HipRenderer(local_dev)
+    if plain is not None and len(plain.recs) > len(tree.recs):
+        checker.load_scene(sc, plain)
+    else:
+        checker.share_scene(slots[0][0], sc)
+    checker.set_param(RT_PARAM_OVERLAP, 0)
+    cam = lambda i: scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world(i % ORBIT_FRAMES, ORBIT_FRAMES))
+    last = {}
+
+    def step(i):
+        r, out = slots[i % IN_FLIGHT]
+        if sequence:
+            r.set_camera(cam(i))
+        r.render(0, d_out=out.data_ptr())
+        last[i % IN_FLIGHT] = i
+
+    torch.cuda.synchronize()
+    for i in range(IN_FLIGHT):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(IN_FLIGHT, IN_FLIGHT + steps):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ok = True
+    want = torch.zeros_like(slots[0][1])
+    for k, i in sorted(last.items()):
+        if sequence:
+            checker.set_camera(cam(i))
+        checker.render(0, d_out=want.data_ptr())
+        checker.sync()
+        ok = ok and bool(torch.equal(slots[k][1], want))
+    rays = 0
+    r0 = slots[0][0]
+    for i in range(IN_FLIGHT, IN_FLIGHT + steps) if sequence else [0]:
+        if sequence:
+            r0.set_camera(cam(i))
+        r0.render(0, d_out=slots[0][1].data_ptr())
+        st = r0.stats()
+        rays += (st["raysClosest"] + st["raysShadow"]) * (1 if sequence else steps)
+    out = {"workload": f"{name}: {wl['text']}", "steps": steps, "warmup": IN_FLIGHT, "frames_in_flight": IN_FLIGHT,
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
+           "rays_per_step": int(rays / steps), "frames_verified": ok,
+           "kd_tree": {"max_depth": depth, "max_prims_in_leaf": leaf, "triangle_refs": int(len(tree.recs)),
+                       "leaves": "pruned (checked against the reference's lists)" if prune > 0 else "the reference's lists"}}
+    checker.close()
+    for r, _ in reversed(slots):
+        r.close()
+    if own:
+        tree.release()
+        if plain is not None:
+            plain.release()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +233,8 @@ def main():
                     help="margin (x scene size) of the leaf pruning of the host builder; 0 = the reference's leaf lists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy (1-GPU runs of a frame workload)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other two workloads that the default single-GPU line carries")
     ap.add_argument("--timed-only", action="store_true",
                     help="for profiler runs: every launch of the frame kernels belongs to the warm-up or the timed steps (no "
                          "frame-alone latency, no in-order pass, no proxy, no check of the pruned leaves), so a profiler's per-kernel average is the timed "
@@ -166,8 +248,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
                          "buffers, one shared scene), so a frame's sparse last passes overlap the next frame's first ones.  "
-                         "0 = 3 (full frame 5.55 / 5.37 / 5.61 ms with 2 / 3 / 4 in flight, 1/8 frame 1.36 / 1.08 / 1.08 ms, "
-                         "fly-through frame 31.2 / 31.0 ms, 1080p frame 0.91 / 0.81 ms)")
+                         "0 = 4 (full frame 5.27 / 5.20 ms with 3 / 4 in flight, half 2.84 / 2.76, quarter 1.65 / 1.51, "
+                         "eighth 1.02 / 0.89 / 1.05 ms with 3 / 4 / 5: four contexts of three streams each are as many "
+                         "streams as the hardware queues take without time-slicing)")
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -220,7 +303,7 @@ def main():
     split = world > 1 and not sequence
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world) if split else sc.h
     def slots_for(parts):
-        return max(1, min(args.in_flight, 4)) if args.in_flight else 3
+        return max(1, min(args.in_flight, 4)) if args.in_flight else IN_FLIGHT
 
     def waves_for(parts, contexts):
         """Waves per CU one traversal pass occupies: all 16 for a frame on its own; with frames in flight 8, and 6 for
@@ -262,34 +345,43 @@ def main():
     rows = r.local_rows
     frame_local = slots[0].frame_local
 
-    # ---- pruned leaf lists are only used when they give the frame of the reference's lists: this rank's share of
-    # the first frame is rendered once with each (a context of its own for the reference's lists) and every pixel
-    # compared on the device, outside the timed region
-    if args.prune_leaves > 0 and len(tree.recs) < ref_refs and not args.timed_only:
+    # ---- the checker: a context of its own that renders one frame at a time, every pass in order on one stream with
+    # nothing beside it, from the REFERENCE's leaf lists when the timed frames use pruned ones.  Before the timed region
+    # it decides whether the pruned lists may be used at all (this rank's share of the first frame, every pixel compared
+    # on the device); after it, every slot's last timed frame is compared with the checker's frame of the same camera.
+    checker, plain = None, None
+    if not args.timed_only:
+        checker = HipRenderer(local_dev)
+        if args.prune_leaves > 0 and len(tree.recs) < ref_refs:
+            plain = FlatTree.build(v, t, args.depth, args.leaf)
+            checker.load_scene(sc, plain)
+        else:
+            checker.share_scene(r, sc)
+        checker.set_param(RT_PARAM_OVERLAP, 0)
+        if split:
+            checker.set_tile(rdist.BAND_H, world, rank)
+
+    def checker_frame(cam=None):
+        if cam is not None:
+            checker.set_camera(cam)
+        out = torch.zeros_like(frame_local)
+        torch.cuda.synchronize()
+        checker.render(0, d_out=out.data_ptr())
+        checker.sync()
+        return out
+
+    if plain is not None:
         cam0 = scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world(rank % ORBIT_FRAMES, ORBIT_FRAMES)) if sequence else None
-        frames = []
-        for which in ("pruned", "reference"):
-            if which == "pruned":
-                rr = r
-            else:
-                plain = FlatTree.build(v, t, args.depth, args.leaf)
-                rr = HipRenderer(local_dev)
-                rr.load_scene(sc, plain)
-                if split:
-                    rr.set_tile(rdist.BAND_H, world, rank)
-            if cam0 is not None:
-                rr.set_camera(cam0)
-            out = torch.zeros_like(frame_local)
-            torch.cuda.synchronize()
-            rr.render(0, d_out=out.data_ptr())
-            rr.sync()
-            frames.append(out)
-            if which == "reference":
-                rr.close()
-                plain.release()
-        if not torch.equal(frames[0], frames[1]):
+        want = checker_frame(cam0)
+        if cam0 is not None:
+            r.set_camera(cam0)
+        got = torch.zeros_like(frame_local)
+        torch.cuda.synchronize()
+        r.render(0, d_out=got.data_ptr())
+        r.sync()
+        if not torch.equal(got, want):
             raise SystemExit("the pruned leaf lists change this frame: run with --prune-leaves 0")
-        del frames
+        del got, want
 
     # ---- frame exchange of the split frame: the library's own RCCL gather (one communicator per frame in flight);
     # torch.distributed's gather (also RCCL) only where that cannot run (gloo rehearsals on one GPU) or fails to
@@ -343,6 +435,7 @@ def main():
 
     def step(i, flags=0):
         sl = slots[i % n_slots]
+        sl.last_step = i
         if sequence:
             sl.r.set_camera(camera_of(i))
         sl.r.render(flags, d_out=sl.frame_local.data_ptr())
@@ -350,13 +443,15 @@ def main():
             sl.r.sync()
             print(f"[rank {rank}] frame rendered", file=sys.stderr, flush=True)
         if not split:
-            return sl.frame_local
-        if use_comm:
+            sl.last_out = sl.frame_local
+        elif use_comm:
             sl.comm.gather(sl.frame_local, sl.frame_full, sc.h, sc.w, rdist.BAND_H, 0, sl.stream.cuda_stream)
-            return sl.frame_full
-        # torch's collective runs on torch's current stream: order it behind this slot's render
-        with torch.cuda.stream(sl.stream):
-            return rdist.gather_frame(sl.frame_local, sc.h, sc.w, rdist.BAND_H)
+            sl.last_out = sl.frame_full
+        else:
+            # torch's collective runs on torch's current stream: order it behind this slot's render
+            with torch.cuda.stream(sl.stream):
+                sl.last_out = rdist.gather_frame(sl.frame_local, sc.h, sc.w, rdist.BAND_H)
+        return sl.last_out
 
     def fence():
         if world > 1:
@@ -396,6 +491,31 @@ def main():
     per_slot = [sl.r.kernel_times_wall() for sl in used]
     launches = per_slot[0][1]
     kms = {k: sum(p[0][k] for p in per_slot) / len(per_slot) for k in per_slot[0][0]}
+
+    # ---- the timed frames are looked at: every slot's last frame (rendered with the others in flight beside it, on the
+    # overlapped schedule and the timed region's grids) against the checker's frame of the same camera, on the device;
+    # on a split frame also what rank 0 assembled against the assembled checker frames
+    frames_verified = None
+    if checker is not None:
+        ok = True
+        ref_cache = {}
+        for sl in used:
+            key = sl.last_step if sequence else 0
+            if key not in ref_cache:
+                ref_cache[key] = checker_frame(camera_of(sl.last_step) if sequence else None)
+            ok = ok and torch.equal(sl.frame_local, ref_cache[key])
+        if split:
+            ref_full = rdist.gather_frame(ref_cache[0], sc.h, sc.w, rdist.BAND_H)        # (collective)
+            if rank == 0:
+                ok = ok and all(torch.equal(sl.last_out, ref_full) for sl in used)
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        frames_verified = bool(int(flag.item()))
+        if not frames_verified:
+            raise SystemExit(f"[rank {rank}] a frame of the timed region differs from the frame rendered on its own "
+                             f"from the reference's leaf lists (this rank's frames equal: {ok})")
+        del ref_cache
 
     # one frame on its own (nothing else in flight): the latency of a frame, as opposed to the step time
     lat = []
@@ -493,6 +613,16 @@ def main():
             sl.r.set_param(RT_PARAM_LAUNCH_WAVES, waves_for(world if split else 1, n_slots))
             sl.r.set_tile(rdist.BAND_H, 1, 0)
 
+    # ---- the other two single-GPU workloads, 5 steps each (so that whoever times this command times them as well)
+    other = None
+    if world == 1 and args.workload == "config3" and not args.timed_only and not args.no_other_configs:
+        other = {"config2": side_workload("config2", local_dev, dev, 22, args.leaf, args.prune_leaves, 5),
+                 # (the fly-through renders the geometry of this workload: same trees)
+                 "config5": side_workload("config5", local_dev, dev, args.depth, args.leaf, args.prune_leaves, 5, tree=tree, plain=plain)}
+        if not all(o["frames_verified"] for o in other.values()):
+            raise SystemExit("a frame of one of the other workloads differs from the frame rendered on its own: "
+                             + json.dumps({k: o["frames_verified"] for k, o in other.items()}))
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / elapsed / 1e6
@@ -508,6 +638,9 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak" if sequence else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # every slot's last timed frame == the same camera's frame rendered alone, passes in order, from the
+            # reference's leaf lists (compared on the device after the timed region; a difference ends the run)
+            "frames_verified": frames_verified,
             "config": {"workload": f"{args.workload}: {wl['text']}",
                        "kd_tree": {"max_depth": args.depth, "max_prims_in_leaf": args.leaf, "depth": int(tree.depth),
                                    "nodes": int(len(tree.nodes)), "triangle_refs": int(len(tree.recs)),
@@ -522,7 +655,7 @@ def main():
                        "rays_per_step": int(rays_total / args.steps), "closest_rays_per_step": int(cnt[0] / args.steps),
                        "shadow_rays_per_step": int(cnt[1] / args.steps),
                        "frames_per_s": round(args.steps * (world if sequence else 1) / elapsed, 3),
-                       "frames_in_flight": n_slots, "frame_latency_ms_alone": round(frame_latency_ms, 4) if lat else None,
+                       "frames_in_flight": n_slots, "warmup_frames_rendered": n_warm, "frame_latency_ms_alone": round(frame_latency_ms, 4) if lat else None,
                        "waves_per_cu_and_pass": {"timed_region": waves_for(world if split else 1, n_slots),
                                                  "frame_alone_and_isolated_passes": lone_waves},
                        "parallelism": "single GPU" if world == 1 else
@@ -557,8 +690,20 @@ def main():
                          "per_ray": {"nodes": round(sst["nodeVisits"] / all_rays, 2), "tri_tests": round(sst["triTests"] / all_rays, 2)},
                          "traversal_stack": {"deepest": int(sst["maxStack"]), "pushes_beyond_lds": int(sst["spillPushes"]),
                                              "rays": int(all_rays)},
-                         "counters": counters},
+                         "counters": counters,
+                         # which committed profiler file backs which figure (written by tools/profile_round.sh on the same frame)
+                         "evidence": {
+                             "achieved_isolated / avg_launch_ms_isolated": PROFILE_TAG + "_kernel_stats_serial.csv: rocprofv3 --kernel-trace "
+                                 "--stats of `bench.py --timed-only --no-overlap --in-flight 1 --launch-waves 16` (one frame at a "
+                                 "time, passes in order): algorithmic_bytes_per_launch / AverageNs of the kernel",
+                             "avg_launch_ms": PROFILE_TAG + "_kernel_stats.csv: the same of `bench.py --timed-only` (launches of the frames in "
+                                 "flight overlap, so these durations add up to more than the step time)",
+                             "achieved / frac": "HIP events of this run (kernel_wall_ms_per_frame_rank0); no profiler file can back a "
+                                 "wall-attributed time; ms_per_step bounds it from above",
+                             "traffic / counters": PROFILE_TAG + "_counters.json (rocprofv3 --pmc passes, tools/pmc_passes.sh), not measured in this run"}},
         }
+        if other is not None:
+            out["other_configs"] = other
         if proxy is not None:
             out["strong_scaling_proxy"] = proxy
         if world == 1 and not args.no_cpu_baseline:
@@ -569,6 +714,10 @@ def main():
     for sl in all_slots:
         if sl.comm:
             sl.comm.close()
+    if checker is not None:
+        checker.close()
+    if plain is not None:
+        plain.release()
     for sl in reversed(all_slots):               # (the first one owns the scene the others read)
         sl.r.close()
     if world > 1:

@@ -159,6 +159,9 @@ struct Counters
 	Ctr headShade[RT_MAX_SLOTS];          // chunk dispenser of k_light
 	Ctr headShadow[RT_MAX_SLOTS];         // chunk dispenser of k_shadow
 	uint32_t overflow;                    // a list append did not fit its buffer (host reports an error)
+#ifdef RT_EXP_REPLAY
+	Ctr rayCountAlt[RT_MAX_SLOTS];        // development build: where a replayed pass counts the child rays it throws away
+#endif
 #ifdef RT_PROFILE_CHUNKS
 	// development build: per slot, histogram of chunk durations (10 us bins) and wave-level round counts
 	uint32_t chunkHist[RT_MAX_SLOTS][64];
@@ -193,6 +196,12 @@ struct Work
 	uint32_t npix, tilesX, nChunks0, spillStride;
 	uint32_t cap;                         // entries per ray list / hit list (npix + room for reservation holes)
 	uint32_t exactAppends;                // 1 = lists are appended without block reservations (no holes: a list of cap = npix entries cannot overflow)
+#ifdef RT_EXP_REPLAY
+	// Development build (timing experiment, see enqueue_replay): the passes of ALL slots of a frame run side by side
+	// over the ray lists a normal frame left behind; child rays go to a second set of lists that nobody reads.
+	uint32_t replay;
+	size_t altOffset;                     // entries between a ray list and its throw-away twin
+#endif
 };
 
 struct Ray { f3 src, dest, inv; };
@@ -1383,8 +1392,14 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 		bool mine = want && target == s;
 		if ( __ballot( mine ) == 0ull )
 			continue;
+#ifdef RT_EXP_REPLAY
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap + ( W.replay ? W.altOffset : 0 );
+		uint32_t *const counter = W.replay ? &W.ctr->rayCountAlt[s].v : &W.ctr->rayCount[s].v;
+#else
 		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
-		uint32_t idx = list_append( &W.ctr->rayCount[s].v, rv[s], mine, block,
+		uint32_t *const counter = &W.ctr->rayCount[s].v;
+#endif
+		uint32_t idx = list_append( counter, rv[s], mine, block,
 			[&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
 		if ( mine && idx >= W.cap )
 			W.ctr->overflow = 2u;                    // (2 = ray list) reported by the host; the ray is dropped
@@ -1419,7 +1434,11 @@ DEVI void closest_out_close( const Work &W, int slot, ClosestOut &o )
 #pragma unroll
 	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
 	{
+#ifdef RT_EXP_REPLAY
+		const size_t lbase = (size_t) ( s - 1 ) * W.cap + ( W.replay ? W.altOffset : 0 );
+#else
 		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
+#endif
 		list_close( o.rays[s], [&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
 	}
 }
@@ -1513,6 +1532,9 @@ DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantId
 		const float alpha = mat.color.a;
 
 		sp = slot == 0 ? 0 : (int) W.stackPos[rh.pix];
+#ifdef RT_EXP_REPLAY
+		if ( W.replay ) sp = slot;          // (a chain of reflections: the pixel's last slot when this one was first processed)
+#endif
 
 		// reflection ray :643-655
 		if ( ( ( sp + 1 ) < S.stackSize ) && ( bNearest != -1 ) && ( ( refl.x + refl.y + refl.z ) > 0.0f ) )
@@ -1540,6 +1562,9 @@ DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantId
 				cRefr = F3( mat.color.r * lf, mat.color.g * lf, mat.color.b * lf );
 			}
 		}
+#ifdef RT_EXP_REPLAY
+		if ( !W.replay )
+#endif
 		if ( slot == 0 || pushRefl || pushRefr )
 			W.stackPos[rh.pix] = (uint32_t) sp;
 	}
@@ -1551,7 +1576,12 @@ DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantId
 		const size_t o = (size_t) slot * W.npix + rh.pix;
 		W.res[o] = make_float4( 0.0f, 0.0f, 0.0f, __int_as_float( parent_of( rh.pk ) ) );
 		if ( slot == 0 )
+		{
+#ifdef RT_EXP_REPLAY
+			if ( !W.replay )
+#endif
 			W.stackPos[rh.pix] = 0u;
+		}
 		else
 		{
 			f3 fw = fold_weight( W, slot, e, rh.pk, F3( 0.0f, 0.0f, 0.0f ) );
@@ -1991,6 +2021,10 @@ struct rt_hip_ctx
 	uint32_t validPixels = 0;
 	Counters *lastCtr = nullptr;  // counters of the frame enqueued last (either entry point): where its overflow flag is read
 	uint32_t lastCap = 0;
+#ifdef RT_EXP_REPLAY
+	int replay = 0;               // set_param key 100
+	hipEvent_t evRepStart = nullptr, evRepDone[RT_MAX_SLOTS] = {};
+#endif
 	SceneTag *tag = nullptr;      // generation of the scene this context holds (and may lend)
 	SceneTag *lender = nullptr;   // rt_hip_share_scene: the lender's tag and its generation at that time
 	uint64_t lenderGen = 0;
@@ -2458,6 +2492,20 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 		c->coopCap = value;
 		return 0;
 	}
+#ifdef RT_EXP_REPLAY
+	if ( key == 100 )
+	{
+		c->replay = value;
+		if ( value && !c->evRepStart )
+		{
+			HIPCHK( hipSetDevice( c->device ) );
+			HIPCHK( hipEventCreateWithFlags( &c->evRepStart, hipEventDisableTiming ) );
+			for ( int k = 0; k < RT_MAX_SLOTS; ++k )
+				HIPCHK( hipEventCreateWithFlags( &c->evRepDone[k], hipEventDisableTiming ) );
+		}
+		return 0;
+	}
+#endif
 	return fail( "rt_hip_set_param: unknown key %d", key );
 }
 
@@ -2501,7 +2549,11 @@ static int prepare_work( rt_hip_ctx *c )
 	// fewer than 64 of its RT_RESV_BLOCK entries unused, and every wave leaves at
 	// most one unfinished reservation behind: that bounds the holes.
 	const size_t cap = list_capacity( c, npix );
+#ifdef RT_EXP_REPLAY
+	if ( ensure( c, c->rays, 2 * 4 * sizeof( float4 ) * cap * (size_t) ( slots > 1 ? slots - 1 : 1 ) ) ) return 1;
+#else
 	if ( ensure( c, c->rays, 4 * sizeof( float4 ) * cap * (size_t) ( slots > 1 ? slots - 1 : 1 ) ) ) return 1;
+#endif
 	if ( ensure( c, c->hitA, sizeof( float4 ) * cap * slots ) ) return 1;
 	if ( ensure( c, c->hitB, sizeof( uint2 ) * cap * slots ) ) return 1;
 	if ( ensure( c, c->hitN, sizeof( float4 ) * cap * slots ) ) return 1;
@@ -2512,13 +2564,21 @@ static int prepare_work( rt_hip_ctx *c )
 	if ( ensure( c, c->hitId, sizeof( int32_t ) * npix ) ) return 1;
 	if ( ensure( c, c->frame, sizeof( rt_argb ) * npix ) ) return 1;
 	// one strip for the closest-hit chain and one per auxiliary stream
+#ifdef RT_EXP_REPLAY
+	if ( ensure( c, c->spill, ( 1 + RT_AUX_STREAMS + RT_MAX_SLOTS ) * sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
+#else
 	if ( ensure( c, c->spill, ( 1 + RT_AUX_STREAMS ) * sizeof( uint2 ) * (size_t) c->maxGrid * RT_BLOCK * RT_SPILL_CAP ) ) return 1;
+#endif
 	size_t per = cap * (size_t) ( slots > 1 ? slots - 1 : 1 );
 	W.ctr = (Counters *) c->ctr.p;
 	W.rayA = (float4 *) c->rays.p;
 	W.rayB = W.rayA + per;
 	W.rayC = W.rayB + per;
 	W.rayD = W.rayC + per;
+#ifdef RT_EXP_REPLAY
+	W.altOffset = 4 * per;
+	W.replay = 0u;
+#endif
 	W.hitA = (float4 *) c->hitA.p;
 	W.hitB = (uint2 *) c->hitB.p;
 	W.hitN = (float4 *) c->hitN.p;
@@ -2540,6 +2600,9 @@ static int prepare_work( rt_hip_ctx *c )
 }
 
 static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned flags, bool overlap, int gridCap );
+#ifdef RT_EXP_REPLAY
+static int enqueue_replay( rt_hip_ctx *c, const Work &W, rt_argb *out );
+#endif
 
 int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 {
@@ -2557,6 +2620,9 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 	if ( (unsigned long long) list_capacity( c, (size_t) c->S.w * c->S.localH ) * (unsigned long long) ( c->S.nLights > 0 ? c->S.nLights : 1 ) >= ( 1ull << 31 ) )
 		return fail( "rt_hip_render: pixels x lights exceeds the 31-bit work-item range" );
 	if ( ( c->workDirty || c->workLights != c->S.nLights ) && prepare_work( c ) ) return 1;
+#ifdef RT_EXP_REPLAY
+	if ( c->replay ) return enqueue_replay( c, c->W, d_out ? (rt_argb *) d_out : (rt_argb *) c->frame.p );
+#endif
 	return enqueue_frame( c, c->W, d_out ? (rt_argb *) d_out : (rt_argb *) c->frame.p, flags, c->overlap && c->S.stackSize > 1, 0 );
 }
 
@@ -2656,6 +2722,56 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 	HIPCHK( hipGetLastError() );
 	return 0;
 }
+
+#ifdef RT_EXP_REPLAY
+// Timing experiment (development build): what would a frame cost if no pass had to wait for the pass of the slot
+// before it?  The ray lists of the frame rendered last on this context are still in place; every slot's closest-hit
+// pass is run again over its list, the slots side by side on the context's three streams (more streams per context
+// make the runtime time-slice its hardware queues), each followed by its shadow and lighting pass; child rays are
+// appended to throw-away lists.  The passes do exactly the work of a normal frame
+// (same lists, same hits, same image); only the order constraints between slots are gone - including the true ones
+// (a child ray after its parent), so this bounds from below what any schedule of the same passes can reach.
+static int enqueue_replay( rt_hip_ctx *c, const Work &W0, rt_argb *out )
+{
+	const DevScene &S = c->S;
+	hipStream_t s = c->stream;
+	Work W = W0;
+	W.replay = 1u;
+	// everything but the lengths of the ray lists starts again
+	Counters *d = W.ctr;
+	HIPCHK( hipMemsetAsync( (char *) d + offsetof( Counters, headClosest ), 0, offsetof( Counters, overflow ) - offsetof( Counters, headClosest ), s ) );
+	HIPCHK( hipMemsetAsync( d->rayCountAlt, 0, sizeof( d->rayCountAlt ), s ) );
+	HIPCHK( hipEventRecord( c->evRepStart, s ) );
+	const int lights = S.nLights > 0 ? S.nLights : 1;
+	for ( int k = 0; k < S.stackSize; ++k )
+	{
+		const int lane = k % ( 1 + RT_AUX_STREAMS );
+		hipStream_t x = lane == 0 ? s : c->aux[lane - 1];
+		if ( lane != 0 && k < 1 + RT_AUX_STREAMS ) HIPCHK( hipStreamWaitEvent( x, c->evRepStart, 0 ) );
+		Work Wk = W;
+		Wk.spill = W.spill + (size_t) ( 1 + RT_AUX_STREAMS + k ) * W.spillStride * RT_SPILL_CAP;
+		Wk.coopLive = c->coopLive ? (uint32_t) c->coopLive | ( (uint32_t) c->coopFill << 8 ) | ( c->coopAtOnce ? 0x80000000u : 0u ) : 0u;
+		Wk.coopCap = (uint32_t) c->coopCap;
+		const uint32_t want = k == 0 ? W.nChunks0 : 0u;
+		int gc = c->gridClosest[0][0], gw = c->gridShadow[0], gl = c->gridLight;
+		const int most = c->launchWaves * c->numCU;
+		if ( gc > most ) gc = most;
+		if ( gw > most ) gw = most;
+		if ( k == 0 && want < (uint32_t) gc ) gc = (int) ( want ? want : 1u );
+		if ( k == 0 && want * (uint32_t) lights < (uint32_t) gw ) gw = (int) ( want ? want * lights : 1u );
+		if ( k == 0 && want < (uint32_t) gl ) gl = (int) ( want ? want : 1u );
+		hipLaunchKernelGGL( ( k_closest<false, RT_WAVES_CLOSEST> ), dim3( gc ), dim3( RT_BLOCK ), 0, x, S, Wk, k, 0 );
+		hipLaunchKernelGGL( k_shadow<false>, dim3( gw ), dim3( RT_BLOCK ), 0, x, S, Wk, k );
+		hipLaunchKernelGGL( k_light, dim3( gl ), dim3( RT_BLOCK ), 0, x, S, Wk, k );
+		if ( lane != 0 ) HIPCHK( hipEventRecord( c->evRepDone[k], x ) );
+	}
+	for ( int k = 0; k < S.stackSize; ++k )
+		if ( k % ( 1 + RT_AUX_STREAMS ) != 0 ) HIPCHK( hipStreamWaitEvent( s, c->evRepDone[k], 0 ) );
+	hipLaunchKernelGGL( k_fold, dim3( ( W.npix + RT_BLOCK - 1 ) / RT_BLOCK ), dim3( RT_BLOCK ), 0, s, W, out, S.stackSize );
+	HIPCHK( hipGetLastError() );
+	return 0;
+}
+#endif
 
 static int check_overflow( rt_hip_ctx *c );
 

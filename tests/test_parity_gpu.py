@@ -437,6 +437,80 @@ def test_config5_4k_frame_sampled_against_oracle():
     tree.release()
 
 
+def test_config4_shares_of_the_benchmark_frame_assemble_to_the_full_frame():
+    """Config 4 as far as one GPU can take it: the 1M-triangle 4K frame on the benchmark's tree (depth 26, leaves of
+    at most 12, pruned lists), cut into bands of 16 rows for 2, 4 and 8 ranks.  Every rank's share is rendered with
+    the schedule bench.py gives a rank (three contexts in flight on one shared scene, overlapped passes, 8 waves per
+    CU and pass for half a frame, 6 below that), the shares are laid out as the exchange lays them out and put
+    together by the library's own de-interleave kernel: the result is the full frame rendered alone, bit for bit,
+    and the shares together trace exactly its rays."""
+    import ctypes as C
+
+    import torch
+    from raytracing_amd import dist as rdist
+    from raytracing_amd._lib import check, lib
+    from raytracing_amd.pipe import RT_PARAM_LAUNCH_WAVES, RT_PARAM_OVERLAP
+    sc = scenes.config3()
+    v, t = sc.flatten()
+    tree = FlatTree.build(v, t, 26, 12, prune_leaves=1e-5)
+    plain = FlatTree.build(v, t, 26, 12)
+    assert len(tree.recs) < len(plain.recs)
+    # the full frame, one at a time, passes in order, from the reference's leaf lists
+    alone = HipRenderer(0)
+    alone.load_scene(sc, plain)
+    alone.set_param(RT_PARAM_OVERLAP, 0)
+    full = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    alone.render(0, d_out=full.data_ptr())
+    want_rays = alone.stats()
+    alone.close()
+    plain.release()
+    assert bool(full.any())
+
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    ctx = []
+    for k, s in enumerate(streams):
+        r = HipRenderer(0, stream=s.cuda_stream)
+        if k == 0:
+            r.load_scene(sc, tree)
+        else:
+            r.share_scene(ctx[0], sc)
+        ctx.append(r)
+    L = lib()
+    L.rt_hip_deinterleave.restype = C.c_int
+    for parts in (2, 4, 8):
+        pad = rdist.padded_rows(sc.h, rdist.BAND_H, parts)
+        assert pad == L.rt_hip_gather_rows(sc.h, rdist.BAND_H, parts)
+        stage = torch.zeros((parts, pad, sc.w, 4), dtype=torch.uint8, device="cuda")
+        got = torch.zeros_like(full)
+        for r in ctx:
+            r.set_param(RT_PARAM_LAUNCH_WAVES, 8 if parts <= 2 else 6)
+        torch.cuda.synchronize()
+        # shares in flight: part p on context p mod 3, nothing waited for in between (two rounds, so that every
+        # context renders with the others' frames beside it from start to end)
+        for rnd in range(2):
+            for p in range(parts):
+                r = ctx[p % 3]
+                r.set_tile(rdist.BAND_H, parts, p)
+                r.render(0, d_out=stage[p].data_ptr())
+        torch.cuda.synchronize()
+        check(L.rt_hip_deinterleave(C.c_void_p(stage.data_ptr()), C.c_void_p(got.data_ptr()), sc.w, sc.h, rdist.BAND_H, parts,
+                                    None), "rt_hip_deinterleave")
+        torch.cuda.synchronize()
+        assert torch.equal(got, full), parts
+        rays = dict(raysClosest=0, raysShadow=0, hits=0)
+        for p in range(parts):
+            ctx[0].set_tile(rdist.BAND_H, parts, p)
+            ctx[0].render(0, d_out=stage[p].data_ptr())
+            st = ctx[0].stats()
+            for k in rays:
+                rays[k] += st[k]
+        assert rays == {k: want_rays[k] for k in rays}, parts
+    for r in reversed(ctx):
+        r.close()
+    tree.release()
+
+
 def test_default_scene_at_its_built_in_size():
     """The reference's demo frame (main.c:19-31: 1280x768, 150x150 water quads,
     ten spheres) at the reference's tree limits, every pixel against the oracle."""

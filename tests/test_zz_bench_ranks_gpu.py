@@ -41,6 +41,8 @@ def test_two_ranks_on_one_gpu_trace_the_same_frame():
     assert two["cpu_baseline"] is None and two["roofline"]["traffic"] is None
     assert "bands of 16 rows over 2 GPUs" in two["config"]["parallelism"]
     assert two["value"] > 0 and two["ms_per_step"] > 0
+    # every slot's last timed frame was compared with the frame rendered alone (both ranks' shares, and what rank 0 assembled)
+    assert one["frames_verified"] is True and two["frames_verified"] is True
 
 
 def test_single_rank_line_has_what_the_contract_asks_for():
@@ -50,16 +52,18 @@ def test_single_rank_line_has_what_the_contract_asks_for():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in b, k
-    assert b["vs_baseline"] is None and b["dtype"] == "f32" and b["config"]["frames_in_flight"] == 3
+    assert b["vs_baseline"] is None and b["dtype"] == "f32" and b["config"]["frames_in_flight"] == 4 and b["frames_verified"] is True
     r = b["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     wall = b["kernel_wall_ms_per_frame_rank0"]
     assert all(0 < wall[k] <= b["ms_per_step"] * 1.02 for k in ("closest", "shadow", "shade"))
     assert wall["closest"] <= b["kernel_ms_per_frame_rank0"]["closest"] * 1.001
     p = b["strong_scaling_proxy"]
-    assert p["part_0_of_8_frames_in_flight"] == 3 and p["part_0_of_2_frames_in_flight"] == 3
+    assert p["part_0_of_8_frames_in_flight"] == 4 and p["part_0_of_2_frames_in_flight"] == 4
+    assert set(r["evidence"]) >= {"achieved_isolated / avg_launch_ms_isolated", "avg_launch_ms"}
     assert 0 < p["part_0_of_8_ms"] < p["part_0_of_2_ms"] < 1.2 * b["ms_per_step"]
     t = run_bench(1, 0, ["--timed-only"])
     assert t["strong_scaling_proxy"] is None if "strong_scaling_proxy" in t else True
     assert t["kernel_ms_per_frame_isolated_rank0"] is None and t["config"]["frame_latency_ms_alone"] is None
+    assert t["frames_verified"] is None                   # (a profiler run contains warm-up and timed frames only)
     assert t["config"]["rays_per_step"] == b["config"]["rays_per_step"]

@@ -13,7 +13,7 @@ E = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ov = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 sc = scenes.config3()
 v, t = sc.flatten()
-tree = FlatTree.build(v, t, 26, 12)
+tree = FlatTree.build(v, t, 26, 12, prune_leaves=float(os.environ.get("RT_PRUNE", "1e-5")))
 if os.environ.get('BUILD_FIRST'):
     from raytracing_amd.pipe import DeviceTree
     for _ in range(int(os.environ['BUILD_FIRST'])):
