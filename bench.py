@@ -165,12 +165,6 @@ def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, pl
             r.share_scene(slots[0][0], sc)
         r.set_param(RT_PARAM_LAUNCH_WAVES, 8)
         slots.append((r, torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8, device=dev)))
-    checker = HipRenderer(local_dev)
-    if plain is not None and len(plain.recs) > len(tree.recs):
-        checker.load_scene(sc, plain)
-    else:
-        checker.share_scene(slots[0][0], sc)
-    checker.set_param(RT_PARAM_OVERLAP, 0)
     cam = lambda i: scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world(i % ORBIT_FRAMES, ORBIT_FRAMES))
     last = {}
 
@@ -190,6 +184,13 @@ def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, pl
         step(i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # (the checker's streams only exist once the timed steps are over)
+    checker = HipRenderer(local_dev)
+    if plain is not None and len(plain.recs) > len(tree.recs):
+        checker.load_scene(sc, plain)
+    else:
+        checker.share_scene(slots[0][0], sc)
+    checker.set_param(RT_PARAM_OVERLAP, 0)
     ok = True
     want = torch.zeros_like(slots[0][1])
     for k, i in sorted(last.items()):
@@ -349,30 +350,38 @@ def main():
     # nothing beside it, from the REFERENCE's leaf lists when the timed frames use pruned ones.  Before the timed region
     # it decides whether the pruned lists may be used at all (this rank's share of the first frame, every pixel compared
     # on the device); after it, every slot's last timed frame is compared with the checker's frame of the same camera.
-    checker, plain = None, None
-    if not args.timed_only:
-        checker = HipRenderer(local_dev)
-        if args.prune_leaves > 0 and len(tree.recs) < ref_refs:
-            plain = FlatTree.build(v, t, args.depth, args.leaf)
-            checker.load_scene(sc, plain)
-        else:
-            checker.share_scene(r, sc)
-        checker.set_param(RT_PARAM_OVERLAP, 0)
-        if split:
-            checker.set_tile(rdist.BAND_H, world, rank)
+    # The checker only exists while it is used: a context's streams take hardware queues, and with more streams in
+    # the process than queues (16) streams share queues and the frames in flight queue up behind each other (step time
+    # 5.54 against 5.20 ms with the checker's three streams left open beside four contexts).
+    plain = None
+    if not args.timed_only and args.prune_leaves > 0 and len(tree.recs) < ref_refs:
+        plain = FlatTree.build(v, t, args.depth, args.leaf)
 
-    def checker_frame(cam=None):
+    def open_checker():
+        ck = HipRenderer(local_dev)
+        if plain is not None:
+            ck.load_scene(sc, plain)
+        else:
+            ck.share_scene(r, sc)
+        ck.set_param(RT_PARAM_OVERLAP, 0)
+        if split:
+            ck.set_tile(rdist.BAND_H, world, rank)
+        return ck
+
+    def checker_frame(ck, cam=None):
         if cam is not None:
-            checker.set_camera(cam)
+            ck.set_camera(cam)
         out = torch.zeros_like(frame_local)
         torch.cuda.synchronize()
-        checker.render(0, d_out=out.data_ptr())
-        checker.sync()
+        ck.render(0, d_out=out.data_ptr())
+        ck.sync()
         return out
 
     if plain is not None:
         cam0 = scenes.make_camera(sc.w, sc.h, world=scenes.orbit_world(rank % ORBIT_FRAMES, ORBIT_FRAMES)) if sequence else None
-        want = checker_frame(cam0)
+        ck = open_checker()
+        want = checker_frame(ck, cam0)
+        ck.close()
         if cam0 is not None:
             r.set_camera(cam0)
         got = torch.zeros_like(frame_local)
@@ -496,14 +505,16 @@ def main():
     # overlapped schedule and the timed region's grids) against the checker's frame of the same camera, on the device;
     # on a split frame also what rank 0 assembled against the assembled checker frames
     frames_verified = None
-    if checker is not None:
+    if not args.timed_only:
         ok = True
         ref_cache = {}
+        ck = open_checker()
         for sl in used:
             key = sl.last_step if sequence else 0
             if key not in ref_cache:
-                ref_cache[key] = checker_frame(camera_of(sl.last_step) if sequence else None)
+                ref_cache[key] = checker_frame(ck, camera_of(sl.last_step) if sequence else None)
             ok = ok and torch.equal(sl.frame_local, ref_cache[key])
+        ck.close()
         if split:
             ref_full = rdist.gather_frame(ref_cache[0], sc.h, sc.w, rdist.BAND_H)        # (collective)
             if rank == 0:
@@ -613,16 +624,6 @@ def main():
             sl.r.set_param(RT_PARAM_LAUNCH_WAVES, waves_for(world if split else 1, n_slots))
             sl.r.set_tile(rdist.BAND_H, 1, 0)
 
-    # ---- the other two single-GPU workloads, 5 steps each (so that whoever times this command times them as well)
-    other = None
-    if world == 1 and args.workload == "config3" and not args.timed_only and not args.no_other_configs:
-        other = {"config2": side_workload("config2", local_dev, dev, 22, args.leaf, args.prune_leaves, 5),
-                 # (the fly-through renders the geometry of this workload: same trees)
-                 "config5": side_workload("config5", local_dev, dev, args.depth, args.leaf, args.prune_leaves, 5, tree=tree, plain=plain)}
-        if not all(o["frames_verified"] for o in other.values()):
-            raise SystemExit("a frame of one of the other workloads differs from the frame rendered on its own: "
-                             + json.dumps({k: o["frames_verified"] for k, o in other.items()}))
-
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / elapsed / 1e6
@@ -702,24 +703,35 @@ def main():
                                  "wall-attributed time; ms_per_step bounds it from above",
                              "traffic / counters": PROFILE_TAG + "_counters.json (rocprofv3 --pmc passes, tools/pmc_passes.sh), not measured in this run"}},
         }
-        if other is not None:
-            out["other_configs"] = other
         if proxy is not None:
             out["strong_scaling_proxy"] = proxy
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, v, t, tree, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     for sl in all_slots:
         if sl.comm:
             sl.comm.close()
-    if checker is not None:
-        checker.close()
-    if plain is not None:
-        plain.release()
     for sl in reversed(all_slots):               # (the first one owns the scene the others read)
         sl.r.close()
+
+    # ---- the other two single-GPU workloads, 5 steps each (so that whoever times this command times them as well);
+    # after this workload's contexts have been closed: their streams would share hardware queues with the new ones
+    other = None
+    if world == 1 and args.workload == "config3" and not args.timed_only and not args.no_other_configs:
+        other = {"config2": side_workload("config2", local_dev, dev, 22, args.leaf, args.prune_leaves, 5),
+                 # (the fly-through renders the geometry of this workload: same trees)
+                 "config5": side_workload("config5", local_dev, dev, args.depth, args.leaf, args.prune_leaves, 5, tree=tree, plain=plain)}
+        if not all(o["frames_verified"] for o in other.values()):
+            raise SystemExit("a frame of one of the other workloads differs from the frame rendered on its own: "
+                             + json.dumps({k: o["frames_verified"] for k, o in other.items()}))
+
+    if plain is not None:
+        plain.release()
+    if rank == 0:
+        if other is not None:
+            out["other_configs"] = other
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

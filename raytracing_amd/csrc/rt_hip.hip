@@ -61,13 +61,19 @@
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK  12     // traversal stack entries per lane kept in LDS
 #endif
-// Resident waves per SIMD the closest-hit kernel is compiled for: 4 (128 VGPRs).
-// A second build for 5 waves (96 VGPRs, spilling to scratch) used to serve frames
-// of RT_BIG_FRAME pixels and more; with the cooperative walk in the kernel it spills
-// in the loops and is slower than this one at every size, so both names now select
-// the same build.
+// Resident waves per SIMD the traversal kernels are compiled for: 5 (96 vector registers), without scratch
+// memory.  What made room for the fifth wave was not the traversal itself but what sat beside it for the whole
+// launch: values that are the same for every ray (scene-box planes, camera origin and matrices, pixel scale,
+// division constants, the address of the lane's stack-overflow strip) are hoisted out of the chunk loop by the
+// compiler, and uniform FLOAT values live in vector registers on this ISA; the scalar registers were oversubscribed
+// by kernel arguments, seven reservation cursors and the list addresses derived from them, and scalar overflow is
+// kept in vector registers as well.  Now the host derives the per-frame constants (derive_scene), the camera
+// matrices are read from device memory where a chunk's rays are made, the cursors live in LDS, child rays are
+// appended in a loop over the slots that occur instead of an unrolled one over all, and wave-uniform values are
+// declared as such (wave_bcast): 119 -> 96 registers for k_closest, 105 -> 89 for k_shadow, step time of the
+// benchmark frame -5.5 % (measured with a 96-register build that still spilled 80 B per lane outside its loops).
 #ifndef RT_WAVES_CLOSEST
-#define RT_WAVES_CLOSEST 4
+#define RT_WAVES_CLOSEST 5
 #endif
 #ifndef RT_WAVES_CLOSEST_STATS
 #define RT_WAVES_CLOSEST_STATS 3     // the counting build needs more registers
@@ -79,7 +85,10 @@
 #define RT_BIG_FRAME 0xffffffffu
 #endif
 #ifndef RT_WAVES_SHADOW
-#define RT_WAVES_SHADOW  4   // the same for the shadow kernel
+#define RT_WAVES_SHADOW  5   // the same for the shadow kernel
+#endif
+#ifndef RT_WAVES_SHADOW_STATS
+#define RT_WAVES_SHADOW_STATS 4
 #endif
 #define RT_SPILL_CAP  (RT_HIP_MAX_TREE_DEPTH - RT_LDS_STACK)
 #define RT_MAX_SLOTS  RT_STACK_SIZE_MAX
@@ -140,6 +149,17 @@ struct DevScene
 	const float4 *lights;     // 3 x float4: (col b,g,r,a) (pos.xyz,_) (rad,_,_,_)
 	float bbC[3], bbE[3];
 	float world[16], vtp[16];
+	// Derived on the host when a frame is enqueued (derive_scene), with the very fp32 operations the kernels
+	// would otherwise repeat: values that are the same for every ray are operands from scalar registers this
+	// way; computed in the kernel they are hoisted out of its loops into vector registers that stay occupied
+	// for the whole launch (17 of them).
+	float bbLo[3], bbHi[3];   // bbC - bbE, bbC + bbE (the planes of CL/rt_intersection.cl:170-187)
+	float xTr, yTr;           // 2 / (w - 1), 2 / (h - 1) (CL/rt_raytrace.cl:27-28)
+	float camSrc[3];          // origin of every camera ray: (0,0,0) through the world matrix (CL/rt_raytrace.cl:65-67)
+	// world[16] then vtp[16] again, in device memory (written by k_put_camera at the start of the frame): the
+	// closest-hit pass of slot 0 reads the 18 matrix elements it needs from here when it makes a chunk's rays,
+	// instead of holding them in scalar registers during the traversal
+	const float *cam;
 	int nSpheres, nLights;
 	int w, h;                 // full image
 	int localH, bandH, nParts, part;
@@ -301,7 +321,18 @@ DEVI uint32_t resv_block( const Work &W, uint32_t count )
 // LDS address space.
 __shared__ uint2 g_lds_stack[RT_LDS_STACK * RT_BLOCK];
 
-struct StackRef { uint2 *spill; uint32_t stride; };
+// the part of a wave's traversal stacks beyond LDS: a strip of HBM, [entry][thread of the launch].  Only the
+// wave-uniform base is kept (scalar registers); the lane's own address is worked out when an entry is spilled,
+// which is rare (3 pushes in 10 000 on the benchmark frame)
+struct StackRef { uint2 *base; uint32_t stride; };
+DEVI uint2 *spill_entry( const StackRef &s, int sp )
+{
+	// (the thread number passes through an empty asm statement: otherwise base + thread is a loop-invariant
+	// 64-bit address that occupies two vector registers for the whole launch)
+	uint32_t t = threadIdx.x;
+	asm volatile( "" : "+v"( t ) );
+	return s.base + (size_t) ( sp - RT_LDS_STACK ) * s.stride + t;
+}
 
 // nodeSlots / triSlots: 64 lane-slots per wave-level iteration of the descend /
 // leaf loop, shared among the lanes active in it (lane utilisation = nodes / nodeSlots)
@@ -316,7 +347,7 @@ DEVI void stack_push( const StackRef &s, int sp, uint32_t node, float tFar, Tall
 		g_lds_stack[sp * RT_BLOCK + threadIdx.x] = v;
 	else
 	{
-		s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride] = v;
+		*spill_entry( s, sp ) = v;
 		if ( STATS ) ++tl.spills;
 	}
 	if ( STATS && (uint32_t) ( sp + 1 ) > tl.maxSp ) tl.maxSp = sp + 1;
@@ -327,7 +358,7 @@ DEVI uint2 stack_pop( const StackRef &s, int sp )
 	if ( sp < RT_LDS_STACK )
 		v = g_lds_stack[sp * RT_BLOCK + threadIdx.x];
 	else
-		v = s.spill[(size_t) ( sp - RT_LDS_STACK ) * s.stride];
+		v = *spill_entry( s, sp );
 	return v;
 }
 
@@ -481,12 +512,12 @@ DEVI bool ray_tri( const TriRay &R, const Rec &rc, float &t, float &u, float &v 
 // :156-200
 DEVI bool box_ray( const DevScene &S, const Ray &r, float &tNear, float &tFar )
 {
-	float t1 = ( S.bbC[0] - S.bbE[0] - r.src.x ) * r.inv.x;
-	float t2 = ( S.bbC[0] + S.bbE[0] - r.src.x ) * r.inv.x;
-	float t3 = ( S.bbC[1] - S.bbE[1] - r.src.y ) * r.inv.y;
-	float t4 = ( S.bbC[1] + S.bbE[1] - r.src.y ) * r.inv.y;
-	float t5 = ( S.bbC[2] - S.bbE[2] - r.src.z ) * r.inv.z;
-	float t6 = ( S.bbC[2] + S.bbE[2] - r.src.z ) * r.inv.z;
+	float t1 = ( S.bbLo[0] - r.src.x ) * r.inv.x;
+	float t2 = ( S.bbHi[0] - r.src.x ) * r.inv.x;
+	float t3 = ( S.bbLo[1] - r.src.y ) * r.inv.y;
+	float t4 = ( S.bbHi[1] - r.src.y ) * r.inv.y;
+	float t5 = ( S.bbLo[2] - r.src.z ) * r.inv.z;
+	float t6 = ( S.bbHi[2] - r.src.z ) * r.inv.z;
 	tNear = maxF( maxF( minF( t1, t2 ), minF( t3, t4 ) ), minF( t5, t6 ) );
 	tFar = minF( minF( maxF( t1, t2 ), maxF( t3, t4 ) ), maxF( t5, t6 ) );
 	if ( tFar < 0 )
@@ -717,7 +748,7 @@ DEVI void wave_lds_sync()
 struct Seg
 {
 	uint32_t q, start, j;                 // lanes per segment, first lane of mine, my index in it
-	unsigned long long mask, below;       // lanes of my segment / those before me
+	unsigned long long mask;              // lanes of my segment
 };
 DEVI Seg make_seg( uint32_t q )
 {
@@ -727,7 +758,6 @@ DEVI Seg make_seg( uint32_t q )
 	g.start = l & ~( q - 1u );
 	g.j = l - g.start;
 	g.mask = q >= 64u ? ~0ull : ( ( ( 1ull << q ) - 1ull ) << g.start );
-	g.below = g.mask & ( ( 1ull << l ) - 1ull );
 	return g;
 }
 
@@ -799,7 +829,7 @@ DEVI void seg_expand( const DevScene &S, const Seg &g, const Ray &sr, bool segOn
 		// my place in the new sequence
 		// (the lanes that hold an entry are the first `kept` of the segment)
 		const unsigned long long m2 = __ballot( two );
-		const uint32_t pos = g.j + (uint32_t) __popcll( m2 & g.below );
+		const uint32_t pos = g.j + lanes_below( m2 & g.mask );         // (those of my segment before me)
 		const uint32_t total = kept + (uint32_t) __popcll( m2 & g.mask );
 		const uint32_t inSeg = total < g.q ? total : g.q;
 		const uint32_t over = total - inSeg;
@@ -1230,15 +1260,10 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 // camera ray of pixel (x, y) of the full image, CL/rt_raytrace.cl:27-28,60-79
 DEVI Ray primary_ray( const DevScene &S, int x, int y )
 {
-	float xTr = 2.0f / (float) ( S.w - 1 );
-	float yTr = 2.0f / (float) ( S.h - 1 );
-	const float *W = S.world, *P = S.vtp;
+	const float *W = S.cam, *P = S.cam + 16;
 	Ray r;
-	f3 s = F3( 0.0f, 0.0f, 0.0f );
-	f3 d = F3( xTr * (float) x - 1.0f, yTr * (float) y - 1.0f, 1.0f );
-	r.src = F3( W[0] * s.x + W[4] * s.y + W[8] * s.z + W[12],
-	            W[1] * s.x + W[5] * s.y + W[9] * s.z + W[13],
-	            W[2] * s.x + W[6] * s.y + W[10] * s.z + W[14] );
+	f3 d = F3( S.xTr * (float) x - 1.0f, S.yTr * (float) y - 1.0f, 1.0f );
+	r.src = F3( S.camSrc[0], S.camSrc[1], S.camSrc[2] );
 	d = F3( P[0] * d.x + P[4] * d.y + P[8] * d.z, P[1] * d.x + P[5] * d.y + P[9] * d.z,
 	        P[2] * d.x + P[6] * d.y + P[10] * d.z );
 	d = F3( W[0] * d.x + W[4] * d.y + W[8] * d.z, W[1] * d.x + W[5] * d.y + W[9] * d.z,
@@ -1249,13 +1274,21 @@ DEVI Ray primary_ray( const DevScene &S, int x, int y )
 }
 
 // entry e of slot 0 = lane (e & 63) of the 8x8 pixel tile (e >> 6)
+// ONE_TILE: the calling lanes hold consecutive entries of one chunk, i.e. of one tile (the closest-hit pass)
+template <bool ONE_TILE>
 DEVI bool slot0_pixel( const DevScene &S, const Work &W, uint32_t e, int &x, int &yLocal, int &yGlobal )
 {
-	uint32_t tile = e >> 6, ln = e & 63u;
-	x = (int) ( ( tile % W.tilesX ) * 8u + ( ln & 7u ) );
-	yLocal = (int) ( ( tile / W.tilesX ) * 8u + ( ln >> 3 ) );
-	int band = yLocal / S.bandH;
-	yGlobal = ( band * S.nParts + S.part ) * S.bandH + ( yLocal - band * S.bandH );
+	// (the tile number of a chunk is wave-uniform and is divided in scalar registers; the band height passes
+	// through an empty asm statement so that the constants of the division by it are worked out here, per chunk,
+	// instead of being kept in vector registers for the whole launch)
+	const uint32_t tile = ONE_TILE ? wave_bcast( e >> 6 ) : e >> 6, ln = e & 63u;
+	const uint32_t ty = tile / W.tilesX, tx = tile - ty * W.tilesX;
+	x = (int) ( tx * 8u + ( ln & 7u ) );
+	yLocal = (int) ( ty * 8u + ( ln >> 3 ) );
+	int bandH = S.bandH;
+	asm volatile( "" : "+s"( bandH ) );
+	int band = yLocal / bandH;
+	yGlobal = ( band * S.nParts + S.part ) * bandH + ( yLocal - band * bandH );
 	return x < S.w && yLocal < S.localH && yGlobal < S.h;
 }
 
@@ -1269,12 +1302,13 @@ struct RayHead
 
 DEVI int parent_of( uint32_t pk ) { return ( pk & 0xffu ) == 0xffu ? -1 : (int) ( pk & 0xffu ); }
 
+template <bool ONE_TILE = false>
 DEVI bool load_ray( const DevScene &S, const Work &W, int slot, uint32_t e, uint32_t count, RayHead &rh )
 {
 	if ( slot == 0 )
 	{
 		int x, yl, yg;
-		if ( !slot0_pixel( S, W, e, x, yl, yg ) )
+		if ( !slot0_pixel<ONE_TILE>( S, W, e, x, yl, yg ) )
 			return false;
 		rh.ray = primary_ray( S, x, yg );
 		rh.pix = (uint32_t) yl * (uint32_t) S.w + (uint32_t) x;
@@ -1329,7 +1363,7 @@ DEVI void flush_tally( const Work &W, const Tally &tl, bool shadow )
 DEVI StackRef make_stack( const Work &W )
 {
 	StackRef st;
-	st.spill = W.spill + (size_t) blockIdx.x * RT_BLOCK + threadIdx.x;
+	st.base = W.spill + (size_t) blockIdx.x * RT_BLOCK;
 	st.stride = W.spillStride;
 	return st;
 }
@@ -1359,39 +1393,65 @@ DEVI bool next_chunk( uint32_t *head, unsigned long long total, Grab &g, uint32_
 	// a chunk is 2^shift entries (64, one per lane, except in the cooperative pass)
 	const uint32_t chunks = (uint32_t) ( ( total + ( 1ull << shift ) - 1ull ) >> shift );
 	const uint32_t waves = gridDim.x * ( RT_BLOCK / 64u );
-	const uint32_t wave = blockIdx.x * ( RT_BLOCK / 64u ) + ( threadIdx.x >> 6 );
+	// (wave-uniform, and said so: a value derived from threadIdx counts as per-lane and would take a vector register
+	// for the whole launch)
+	const uint32_t wave = wave_bcast( blockIdx.x * ( RT_BLOCK / 64u ) + ( threadIdx.x >> 6 ) );
 	// dynShare = 8: one static round, the rest through the counter
 	const uint32_t rounds = chunks <= 2u * waves ? ( chunks + waves - 1u ) / waves
 		: ( dynShare >= 8u ? 1u : (uint32_t) ( (unsigned long long) chunks * ( 8u - dynShare ) / ( 8ull * waves ) ) );
-	uint32_t c;
+	// (one way out: `first` and the answer are wave-uniform values of one definition each)
+	uint32_t c = 0xffffffffu;
+	const uint32_t base = rounds * waves;
 	if ( g.round < rounds )
 	{
 		c = g.round * waves + wave;
 		++g.round;
 	}
-	else
+	else if ( base < chunks )
 	{
-		const uint32_t base = rounds * waves;
-		if ( base >= chunks )
-			return false;
 		uint32_t k = 0;
 		if ( lane_id() == 0u )
 			k = atomicAdd( head, 1u );
 		c = base + wave_bcast( k );
 	}
-	first = c << shift;
+	c = wave_bcast( c );
+	first = wave_bcast( c << shift );
 	return c < chunks;
 }
 
-DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
+// Where a wave stands in its reservations: one (next position, end) pair for the hit list of the slot (index 0) and
+// one per ray list the pass can append to (index = slot of the list).  They live in LDS, not in registers: they are
+// needed for a moment at the end of a chunk, and seven pairs plus the list addresses that follow from them, held
+// across the traversal, were a fifth of the kernel's scalar registers (whose overflow goes into vector registers).
+__shared__ uint2 g_lds_resv[( RT_BLOCK / 64 ) * ( RT_MAX_SLOTS + 1 )];
+DEVI uint2 *resv_slot( int k ) { return g_lds_resv + ( threadIdx.x >> 6 ) * ( RT_MAX_SLOTS + 1 ) + k; }
+DEVI Resv resv_load( int k )
 {
-	// lanes of one wave may target different slots: aggregate per slot
-#pragma unroll
-	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
+	const uint2 v = *resv_slot( k );
+	Resv r = { wave_bcast( v.x ), wave_bcast( v.y ) };
+	return r;
+}
+DEVI void resv_store( int k, const Resv &r )
+{
+	if ( lane_id() == 0u )
+		*resv_slot( k ) = make_uint2( r.pos, r.end );
+	wave_lds_sync();
+}
+DEVI void resv_init()
+{
+	if ( lane_id() <= (uint32_t) RT_MAX_SLOTS )
+		*resv_slot( (int) lane_id() ) = make_uint2( 0u, 0u );
+	wave_lds_sync();
+}
+
+DEVI void push_ray( const Work &W, uint32_t block, int target, bool want, const Ray &r, uint32_t pix, int parent, int type, f3 coef, f3 P )
+{
+	// lanes of one wave may target different slots: one aggregated append per slot that occurs
+	unsigned long long todo = __ballot( want );
+	while ( todo != 0ull )
 	{
-		bool mine = want && target == s;
-		if ( __ballot( mine ) == 0ull )
-			continue;
+		const int s = __builtin_amdgcn_readlane( target, (int) ( __ffsll( (long long) todo ) - 1 ) );
+		const bool mine = want && target == s;
 #ifdef RT_EXP_REPLAY
 		const size_t lbase = (size_t) ( s - 1 ) * W.cap + ( W.replay ? W.altOffset : 0 );
 		uint32_t *const counter = W.replay ? &W.ctr->rayCountAlt[s].v : &W.ctr->rayCount[s].v;
@@ -1399,8 +1459,10 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
 		uint32_t *const counter = &W.ctr->rayCount[s].v;
 #endif
-		uint32_t idx = list_append( counter, rv[s], mine, block,
+		Resv rv = resv_load( s );
+		uint32_t idx = list_append( counter, rv, mine, block,
 			[&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
+		resv_store( s, rv );
 		if ( mine && idx >= W.cap )
 			W.ctr->overflow = 2u;                    // (2 = ray list) reported by the host; the ray is dropped
 		else if ( mine )
@@ -1412,6 +1474,7 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 			W.rayC[o] = make_float4( coef.x, coef.y, coef.z, 0.0f );
 			W.rayD[o] = make_float4( P.x, P.y, P.z, 0.0f );
 		}
+		todo &= ~__ballot( mine );
 	}
 }
 
@@ -1419,19 +1482,12 @@ DEVI void push_ray( const Work &W, Resv *rv, uint32_t block, int target, bool wa
 // k_closest: closest-hit pass of one slot
 // ---------------------------------------------------------------------------
 
-// list positions a wave has reserved for what a closest-hit pass appends
-struct ClosestOut
-{
-	Resv hits;                    // hit list of the slot
-	Resv rays[RT_MAX_SLOTS];      // ray lists of the child slots
-	uint32_t block;
-};
-
-DEVI void closest_out_close( const Work &W, int slot, ClosestOut &o )
+// what is left of a wave's reservations when it runs out of chunks is marked as holes
+DEVI void closest_out_close( const Work &W, int slot )
 {
 	const size_t hbase = (size_t) slot * W.cap;
-	list_close( o.hits, [&]( uint32_t i ) { if ( i < W.cap ) W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); } );
-#pragma unroll
+	Resv hits = resv_load( 0 );
+	list_close( hits, [&]( uint32_t i ) { if ( i < W.cap ) W.hitA[hbase + i].x = __uint_as_float( RT_INVALID ); } );
 	for ( int s = 1; s < RT_MAX_SLOTS; ++s )
 	{
 #ifdef RT_EXP_REPLAY
@@ -1439,7 +1495,8 @@ DEVI void closest_out_close( const Work &W, int slot, ClosestOut &o )
 #else
 		const size_t lbase = (size_t) ( s - 1 ) * W.cap;
 #endif
-		list_close( o.rays[s], [&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
+		Resv rays = resv_load( s );
+		list_close( rays, [&]( uint32_t i ) { if ( i < W.cap ) W.rayA[lbase + i].w = __uint_as_float( RT_INVALID ); } );
 	}
 }
 
@@ -1466,7 +1523,7 @@ DEVI SphereHit nearest_sphere( const DevScene &S, const Ray &r )
 // sphere against triangle, the hit record, the shading normal, the child rays, or
 // the finished slot of a miss.  Wave-uniform: every lane of the wave calls it,
 // lanes without a ray with valid = false.
-DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantIds, ClosestOut &out,
+DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantIds, uint32_t block,
 	bool valid, uint32_t e, const RayHead &rh, const NearHit &h, const SphereHit &sph )
 {
 	const size_t hbase = (size_t) slot * W.cap;
@@ -1480,7 +1537,9 @@ DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantId
 	const bool sphHit = valid && ( h.nearestB || prB ) && !( h.minT < prMinT ) && prB;
 	bool hit = triHit || sphHit;
 
-	const uint32_t hidx = list_append( &W.ctr->hitCount[slot].v, out.hits, hit, out.block, holeHit );
+	Resv hits = resv_load( 0 );
+	const uint32_t hidx = list_append( &W.ctr->hitCount[slot].v, hits, hit, block, holeHit );
+	resv_store( 0, hits );
 	if ( hit && hidx >= W.cap )
 	{
 		W.ctr->overflow = 1u;                        // (1 = hit list) reported by the host; the entry is dropped
@@ -1569,8 +1628,8 @@ DEVI void finish_closest( const DevScene &S, const Work &W, int slot, int wantId
 			W.stackPos[rh.pix] = (uint32_t) sp;
 	}
 	// slot numbers: reflection takes the first new slot, refraction the next
-	push_ray( W, out.rays, out.block, sp - ( pushRefr ? 1 : 0 ), pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
-	push_ray( W, out.rays, out.block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
+	push_ray( W, block, sp - ( pushRefr ? 1 : 0 ), pushRefl, rRefl, rh.pix, slot, 1, cRefl, P );
+	push_ray( W, block, sp, pushRefr, rRefr, rh.pix, slot, 0, cRefr, P );
 	if ( !hit && valid )
 	{
 		const size_t o = (size_t) slot * W.npix + rh.pix;
@@ -1632,8 +1691,8 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 	const uint32_t shift = chunk_shift( count, W.coopLive );
 	uint32_t first;
 	Grab grab = { 0u };
-	ClosestOut out = {};
-	out.block = resv_block( W, count );
+	const uint32_t block = resv_block( W, count );
+	resv_init();
 	while ( next_chunk( &W.ctr->headClosest[slot].v, count, grab, first, RT_TRAV_DYN, shift ) )
 	{
 #ifdef RT_PROFILE_CHUNKS
@@ -1642,7 +1701,7 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 		const uint32_t e = first + lane_id();
 		RayHead rh;
 		rh.pix = rh.pk = 0u;
-		const bool valid = lane_id() < ( 1u << shift ) && load_ray( S, W, slot, e, count, rh );
+		const bool valid = lane_id() < ( 1u << shift ) && load_ray<true>( S, W, slot, e, count, rh );
 
 		SphereHit sph = { INFINITY, 0u, 0 };
 		NearHit h = { INFINITY, 0.0f, 0.0f, 0u, 0 };
@@ -1666,7 +1725,7 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 #ifdef RT_PROFILE_CHUNKS
 		const unsigned long long c1 = wall_clock64();
 #endif
-		finish_closest( S, W, slot, wantIds, out, valid, e, rh, h, sph );
+		finish_closest( S, W, slot, wantIds, block, valid, e, rh, h, sph );
 #ifdef RT_PROFILE_CHUNKS
 		if ( lane_id() == 0u )
 		{
@@ -1690,7 +1749,7 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 		}
 #endif
 	}
-	closest_out_close( W, slot, out );
+	closest_out_close( W, slot );
 	if ( STATS )
 		flush_tally( W, tl, false );
 }
@@ -1713,7 +1772,7 @@ DEVI void to_light( const DevScene &S, int o, f3 P, f3 &toLight, float &d )
 // carries the sphere sum keeps it when the ray misses the scene box, so the
 // sphere opacity is then counted twice, as in the reference.
 template <bool STATS>
-__global__ __launch_bounds__( RT_BLOCK, RT_WAVES_SHADOW ) void k_shadow( DevScene S, Work W, int slot )
+__global__ __launch_bounds__( RT_BLOCK, STATS ? RT_WAVES_SHADOW_STATS : RT_WAVES_SHADOW ) void k_shadow( DevScene S, Work W, int slot )
 {
 	const StackRef st = make_stack( W );
 	Tally tl = { 0u, 0u, 0u, 0u, 0.0f, 0.0f };
@@ -1914,6 +1973,14 @@ __global__ __launch_bounds__( RT_BLOCK ) void k_fold( Work W, rt_argb *out, int 
 	out[p] = px;
 }
 
+// the camera matrices of the frame into device memory (DevScene::cam)
+__global__ __launch_bounds__( 64 ) void k_put_camera( DevScene S, float *dst )
+{
+	const uint32_t i = threadIdx.x;
+	if ( i < 16u ) dst[i] = S.world[i];
+	else if ( i < 32u ) dst[i] = S.vtp[i - 16u];
+}
+
 // number of entries of a list that are not reservation holes (statistics only);
 // word = index of the 32-bit word of the float4 that carries the marker
 __global__ __launch_bounds__( RT_BLOCK ) void k_count_valid( const float4 *list, const uint32_t *n, int word, unsigned long long *out )
@@ -1994,6 +2061,7 @@ struct rt_hip_ctx
 	Work W;
 	DevBuf nodes, recs, shade, mats, spheres, sphereMat, lights;
 	DevBuf ctr, rays, hitA, hitB, hitN, res, fac, shadow, stackPos, hitId, spill, frame;
+	DevBuf cam;                   // camera matrices of the frame being rendered (allocated with the context)
 	uint64_t nNodes = 0, nRecs = 0, nTris = 0, nMats = 0;
 	uint64_t maxMatTree = 0, maxMatSphere = 0;   // highest material slot referenced
 	int treeDepth = 0;
@@ -2117,6 +2185,12 @@ rt_hip_ctx *rt_hip_create( int device )
 	}
 	memset( &c->S, 0, sizeof( c->S ) );
 	memset( &c->W, 0, sizeof( c->W ) );
+	if ( ensure( c, c->cam, 32 * sizeof( float ) ) )
+	{
+		rt_hip_destroy( c );
+		return nullptr;
+	}
+	c->S.cam = (const float *) c->cam.p;
 	c->S.stackSize = STACK_SIZE;
 	c->S.bandH = 16;
 	c->S.nParts = 1;
@@ -2182,7 +2256,7 @@ void rt_hip_destroy( rt_hip_ctx *c )
 		if ( c->evHit[k] ) (void) hipEventDestroy( c->evHit[k] );
 		if ( c->evLit[k] ) (void) hipEventDestroy( c->evLit[k] );
 	}
-	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights,
+	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights, &c->cam,
 		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->hitN, &c->res, &c->fac, &c->shadow, &c->stackPos, &c->hitId, &c->spill, &c->frame };
 	for ( DevBuf *b : all )
 		if ( b->p ) (void) hipFree( b->p );
@@ -2195,12 +2269,25 @@ void rt_hip_destroy( rt_hip_ctx *c )
 	delete c;
 }
 
+// A context that runs on the caller's stream gives its own stream back: every stream of the process takes
+// a place among the runtime's hardware queues, and streams beyond their number share queues with others.
 int rt_hip_set_stream( rt_hip_ctx *c, void *s )
 {
 	if ( !c ) return fail( "null context" );
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
-	c->stream = s ? (hipStream_t) s : c->own;
+	if ( s )
+	{
+		if ( c->own )
+		{
+			HIPCHK( hipStreamDestroy( c->own ) );
+			c->own = nullptr;
+		}
+		c->stream = (hipStream_t) s;
+		return 0;
+	}
+	if ( !c->own ) HIPCHK( hipStreamCreate( &c->own ) );
+	c->stream = c->own;
 	return 0;
 }
 
@@ -2599,6 +2686,24 @@ static int prepare_work( rt_hip_ctx *c )
 	return 0;
 }
 
+// the per-frame constants of DevScene that follow from its other fields (same fp32 operations, in the same
+// order, as the expressions they replace in the kernels: this file is compiled without contraction)
+static void derive_scene( DevScene &S )
+{
+	for ( int k = 0; k < 3; ++k )
+	{
+		S.bbLo[k] = S.bbC[k] - S.bbE[k];
+		S.bbHi[k] = S.bbC[k] + S.bbE[k];
+	}
+	S.xTr = 2.0f / (float) ( S.w - 1 );
+	S.yTr = 2.0f / (float) ( S.h - 1 );
+	const float *W = S.world;
+	const float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+	S.camSrc[0] = W[0] * sx + W[4] * sy + W[8] * sz + W[12];
+	S.camSrc[1] = W[1] * sx + W[5] * sy + W[9] * sz + W[13];
+	S.camSrc[2] = W[2] * sx + W[6] * sy + W[10] * sz + W[14];
+}
+
 static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned flags, bool overlap, int gridCap );
 #ifdef RT_EXP_REPLAY
 static int enqueue_replay( rt_hip_ctx *c, const Work &W, rt_argb *out );
@@ -2632,6 +2737,7 @@ int rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags )
 static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned flags, bool overlap, int gridCap )
 {
 	const bool stats = flags & RT_HIP_STATS, ids = flags & RT_HIP_HITIDS, timing = flags & RT_HIP_TIMING;
+	derive_scene( c->S );
 	const DevScene &S = c->S;
 	hipStream_t s = c->stream;
 
@@ -2658,6 +2764,7 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 	if ( timing ) HIPCHK( hipEventRecord( evFrame[0], s ) );
 	c->lastCtr = W.ctr;
 	c->lastCap = W.cap;
+	hipLaunchKernelGGL( k_put_camera, dim3( 1 ), dim3( 64 ), 0, s, S, (float *) c->cam.p );
 	HIPCHK( hipMemsetAsync( W.ctr, 0, sizeof( Counters ), s ) );
 	if ( W.npix == 0 )
 		return 0;
@@ -2733,6 +2840,7 @@ static int enqueue_frame( rt_hip_ctx *c, const Work &W, rt_argb *out, unsigned f
 // (a child ray after its parent), so this bounds from below what any schedule of the same passes can reach.
 static int enqueue_replay( rt_hip_ctx *c, const Work &W0, rt_argb *out )
 {
+	derive_scene( c->S );
 	const DevScene &S = c->S;
 	hipStream_t s = c->stream;
 	Work W = W0;
@@ -2741,6 +2849,7 @@ static int enqueue_replay( rt_hip_ctx *c, const Work &W0, rt_argb *out )
 	Counters *d = W.ctr;
 	HIPCHK( hipMemsetAsync( (char *) d + offsetof( Counters, headClosest ), 0, offsetof( Counters, overflow ) - offsetof( Counters, headClosest ), s ) );
 	HIPCHK( hipMemsetAsync( d->rayCountAlt, 0, sizeof( d->rayCountAlt ), s ) );
+	hipLaunchKernelGGL( k_put_camera, dim3( 1 ), dim3( 64 ), 0, s, S, (float *) c->cam.p );
 	HIPCHK( hipEventRecord( c->evRepStart, s ) );
 	const int lights = S.nLights > 0 ? S.nLights : 1;
 	for ( int k = 0; k < S.stackSize; ++k )
