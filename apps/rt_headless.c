@@ -14,7 +14,7 @@
  *
  *   rt_headless [--frames N] [--size WxH] [--t T] [--dt DT] [--out DIR]
  *               [--format png|ppm|none] [--resume] [--depth D] [--leaf L]
- *               [--stack S] [--squares N] [--obj FILE] [--device N] [--gpu-build | --host-build] [--prune-leaves]
+ *               [--stack S] [--squares N] [--obj FILE] [--device N] [--gpu-build | --host-build] [--prune-leaves | --reference-leaves]
  */
 #include <math.h>
 #include <stdio.h>
@@ -301,7 +301,7 @@ static double now( void )
 
 int main( int argc, char **argv )
 {
-	int frames = 1, w = 1280, h = 768, depth = 0, leaf = 0, stack = 0, squares = 150, device = 0, resume = 0, gpuBuild = -1, prune = 0, i;
+	int frames = 1, w = 1280, h = 768, depth = 0, leaf = 0, stack = 0, squares = 150, device = 0, resume = 0, gpuBuild = -1, prune = -1, i;
 	float t = 0.0f, dT = 0.0001f;
 	unsigned long pngN = 0;
 	const char *out = "pngs", *format = "png", *obj = NULL;
@@ -330,7 +330,8 @@ int main( int argc, char **argv )
 		else if ( !strcmp( a, "--resume" ) ) resume = 1;
 		else if ( !strcmp( a, "--gpu-build" ) ) gpuBuild = 1;
 		else if ( !strcmp( a, "--host-build" ) ) gpuBuild = 0;
-		else if ( !strcmp( a, "--prune-leaves" ) ) prune = 1;
+		else if ( !strcmp( a, "--prune-leaves" ) ) prune = 1;                 /* (the pipe's default) */
+		else if ( !strcmp( a, "--reference-leaves" ) ) prune = 0;
 		else { fprintf( stderr, "unknown option %s\n", a ); return 2; }
 	}
 	if ( frames < 1 || w < 2 || h < 2 || squares < 1 ) { fprintf( stderr, "bad arguments\n" ); return 2; }
@@ -346,7 +347,7 @@ int main( int argc, char **argv )
 	if ( leaf ) rt_render_pipe_set_param( &rp, RT_PARAM_MAX_PRIMS_IN_NODE, leaf );
 	if ( stack ) rt_render_pipe_set_param( &rp, RT_PARAM_STACK_SIZE, stack );
 	if ( gpuBuild >= 0 ) rt_render_pipe_set_param( &rp, RT_PARAM_GPU_BUILD, gpuBuild );
-	if ( prune ) rt_render_pipe_set_param( &rp, RT_PARAM_PRUNE_LEAVES, 1 );
+	if ( prune >= 0 ) rt_render_pipe_set_param( &rp, RT_PARAM_PRUNE_LEAVES, prune );
 
 	/* camera of the demo (main.c:780,815-825) */
 	rt_camera_create( &cam, (float) w / (float) h, 0.125f * (float) M_PI );

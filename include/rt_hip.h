@@ -60,6 +60,13 @@ typedef struct _rt_hip_trishade
 	uint32_t _pad[2];
 } rt_hip_trishade;
 
+/* Where a leaf's COMPLETE list lies when the list its node points to has been pruned (rt_kdtree.h, pruneLeaves):
+ * one entry per node (inner nodes: zeros), first = index into the same record array, behind the pruned lists.
+ * Only rays with a direction component of exactly zero read it: the reference gives such a ray NaN split
+ * distances when its origin lies in a split plane, and what it then returns depends on leaves that list a
+ * triangle they do not contain - so these rays are walked over the reference's lists. */
+typedef struct _rt_hip_leaf_full { uint32_t first, count; } rt_hip_leaf_full;
+
 typedef struct _rt_hip_stats
 {
 	uint64_t raysClosest;   /* closest-hit queries                         */
@@ -104,7 +111,7 @@ typedef struct _rt_hip_stats
                                           12); a ray that needs more restarts its walk from the root.  Lower values
                                           exist to exercise that path.  Same image either way.                      */
 
-#define RT_PARAM_LAUNCH_WAVES       10   /* waves per compute unit that one traversal pass occupies (1..16, default 16 =
+#define RT_PARAM_LAUNCH_WAVES       10   /* waves per compute unit that one traversal pass occupies (1..20, default 16 =
                                           all that fit: a frame rendered on its own is fastest that way).  A caller
                                           that keeps several frames in flight (contexts sharing a scene) sets 8: a
                                           pass that takes every wave slot keeps the other frames' passes out until
@@ -112,10 +119,10 @@ typedef struct _rt_hip_stats
 
 #define RT_PARAM_PRUNE_LEAVES       11   /* 1 = trees built from now on list in a leaf only the triangles that touch its
                                           cell (margin RT_PRUNE_LEAVES_MARGIN x scene size; rt_kdtree.h, pruneLeaves):
-                                          rt_hip_build_tree, and both builders of the render pipe.  Default 0: the
-                                          reference's leaf lists.  Same frame on every scene tested, fewer triangle
-                                          tests; not exact for rays that start in a split plane with a direction
-                                          component of exactly zero.                                               */
+                                          rt_hip_build_tree (default 0), and both builders of the render pipe
+                                          (default 1).  0: the reference's leaf lists only.  Same frame, fewer triangle tests; the
+                                          complete lists are kept behind the pruned ones for the rays whose walk
+                                          depends on them (a direction component of exactly zero).                 */
 #define RT_PRUNE_LEAVES_MARGIN 1e-5f
 
 #define RT_HIP_MAX_TREE_DEPTH 64       /* deepest tree the traversal stack admits */
@@ -132,6 +139,11 @@ int  rt_hip_set_stream( rt_hip_ctx *c, void *hipStream );
 int  rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes,
 	const rt_hip_trirec *recs, uint64_t nRecs, const rt_hip_trishade *shade,
 	uint64_t nTris, const rt_box *bbox, int depth );
+/* The same for a tree with pruned leaf lists: recs holds nRecs + nRecsFull records (the pruned lists the nodes
+ * point to, then the complete ones), leafFull one entry per node.  leafFull = NULL, nRecsFull = 0: as above. */
+int  rt_hip_upload_tree_lists( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes,
+	const rt_hip_trirec *recs, uint64_t nRecs, uint64_t nRecsFull, const rt_hip_leaf_full *leafFull,
+	const rt_hip_trishade *shade, uint64_t nTris, const rt_box *bbox, int depth );
 /* Install a tree built on the device by rt_kdtree_build_device (rt_kdtree.h)
  * without copying: the context takes ownership of the three buffers and
  * clears *t.  Replaces rt_hip_upload_tree for geometry that changes every frame. */

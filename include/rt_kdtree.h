@@ -29,6 +29,11 @@ typedef struct _rt_kdtree_flat
 	rt_hip_trishade *shade;   uint64_t nTris;
 	rt_box bbox;
 	int depth;                /* deepest leaf, root = 0 */
+	/* pruned leaf lists only (else NULL / 0): recs then holds nRecs + nRecsFull records - the pruned lists
+	 * the nodes point to, followed by every leaf's complete list - and leafFull, one entry per node, says
+	 * where a leaf's complete list lies (rt_hip.h) */
+	rt_hip_leaf_full *leafFull;
+	uint64_t nRecsFull;
 } rt_kdtree_flat;
 
 /* Builder options.  With sahStop = 0, allAxes = 0 and pruneLeaves = 0 the tree
@@ -50,7 +55,11 @@ typedef struct _rt_kdtree_flat
  *                (If the reference's partition dropped a triangle - one that
  *                lies in a split plane goes to neither child - the result of
  *                the walk depends on leaves that list a triangle they do not
- *                contain; such a tree keeps the reference's lists.)
+ *                contain; such a tree keeps the reference's lists.  The same
+ *                holds for the walk of a ray with a direction component of
+ *                exactly zero that starts in a split plane: the complete lists
+ *                are therefore kept behind the pruned ones, rt_kdtree_flat::
+ *                leafFull, and the kernels walk such rays over those.)
  *                The margin has to cover the rounding of hit and split
  *                distances: 1e-5 is about 170 units in the last place of a
  *                coordinate at the scene's scale. */
@@ -101,6 +110,9 @@ typedef struct _rt_kdtree_device
 	rt_box bbox;
 	int depth;
 	uint32_t maxMaterial;                /* highest material slot any triangle references */
+	/* pruned leaf lists only (else NULL / 0), as in rt_kdtree_flat: recs then holds nRecs + nRecsFull + 1 records */
+	void *leafFull;                      /* rt_hip_leaf_full, one per node */
+	uint64_t nRecsFull;
 } rt_kdtree_device;
 
 /* Returns 0 on success (1 bad arguments, 2 limits, 3 vertex index out of
@@ -113,7 +125,8 @@ int  rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle *tris, ui
  * pruned in place after the build - a leaf's record range keeps its start, its
  * count drops, nRecs stays what it was - by the host builder's test applied to
  * the vertices the records hold, and not at all when the build dropped a
- * triangle that lies in a split plane.  No reference counterpart. */
+ * triangle that lies in a split plane; a copy of the complete lists is kept
+ * behind them (leafFull, nRecsFull = nRecs).  No reference counterpart. */
 int  rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out );
 void rt_kdtree_device_release( rt_kdtree_device *t );

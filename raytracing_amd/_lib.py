@@ -35,14 +35,16 @@ class FlatTree(C.Structure):      # rt_kdtree_flat
     _fields_ = [("nodes", C.c_void_p), ("nNodes", C.c_uint64),
                 ("recs", C.c_void_p), ("nRecs", C.c_uint64),
                 ("shade", C.c_void_p), ("nTris", C.c_uint64),
-                ("bbox", C.c_float * 8), ("depth", C.c_int)]
+                ("bbox", C.c_float * 8), ("depth", C.c_int),
+                ("leafFull", C.c_void_p), ("nRecsFull", C.c_uint64)]
 
 
 class DeviceTreeStruct(C.Structure):   # rt_kdtree_device
     _fields_ = [("nodes", C.c_void_p), ("nNodes", C.c_uint64),
                 ("recs", C.c_void_p), ("nRecs", C.c_uint64),
                 ("shade", C.c_void_p), ("nTris", C.c_uint64),
-                ("bbox", C.c_float * 8), ("depth", C.c_int), ("maxMaterial", C.c_uint32)]
+                ("bbox", C.c_float * 8), ("depth", C.c_int), ("maxMaterial", C.c_uint32),
+                ("leafFull", C.c_void_p), ("nRecsFull", C.c_uint64)]
 
 
 class BuildOpts(C.Structure):     # rt_kdtree_build_opts
@@ -129,7 +131,7 @@ def lib():
         L.rt_hip_destroy.argtypes = [C.c_void_p]
         L.rt_render_pipe_hip.restype = C.c_void_p
         L.rt_render_pipe_draw.restype = C.c_void_p
-        for name in ("rt_hip_set_stream", "rt_hip_upload_tree", "rt_hip_upload_materials",
+        for name in ("rt_hip_set_stream", "rt_hip_upload_tree", "rt_hip_upload_tree_lists", "rt_hip_upload_materials",
                      "rt_hip_upload_spheres", "rt_hip_upload_lights", "rt_hip_set_camera",
                      "rt_hip_set_image", "rt_hip_set_tile", "rt_hip_share_scene", "rt_hip_render_noalloc", "rt_hip_kernel_times_ex", "rt_hip_kernel_intervals", "rt_hip_local_rows", "rt_hip_set_param",
                      "rt_hip_render", "rt_hip_sync", "rt_hip_read_frame", "rt_hip_read_hit_ids",

@@ -157,10 +157,11 @@ struct BNode
 {
 	BNode *l = nullptr, *r = nullptr;
 	std::vector<uint32_t> prims;     // leaves only
+	std::vector<uint32_t> full;      // leaves of a pruned tree: the complete (reference) list
 	float sep = 0.0f;
 	int axis = 0;
 	bool leaf = false;
-	uint64_t nodes = 1, refs = 0;    // sub-tree totals
+	uint64_t nodes = 1, refs = 0, refsFull = 0;    // sub-tree totals
 	int depth = 0;                   // deepest leaf below, relative to this node
 };
 
@@ -251,6 +252,7 @@ struct Builder
 		node->leaf = true;
 		if ( pruneLeaves > 0.0f )
 		{
+			node->full = prims;
 			size_t k = 0;
 			for ( size_t i = 0; i < prims.size(); ++i )
 			{
@@ -409,6 +411,7 @@ void totals( BNode *n )
 	{
 		n->nodes = 1;
 		n->refs = n->prims.size();
+		n->refsFull = n->full.size();
 		n->depth = 0;
 		return;
 	}
@@ -416,6 +419,7 @@ void totals( BNode *n )
 	totals( n->r );
 	n->nodes = 1 + n->l->nodes + n->r->nodes;
 	n->refs = n->l->refs + n->r->refs;
+	n->refsFull = n->l->refsFull + n->r->refsFull;
 	n->depth = 1 + std::max( n->l->depth, n->r->depth );
 }
 
@@ -431,8 +435,9 @@ void release_tree( BNode *n )
 	delete n;
 }
 
-// pre-order packing, left child right behind its parent (:860-912)
-void pack( BNode *n, uint64_t pos, uint64_t ref, rt_hip_kdnode *nodes, uint32_t *order )
+// pre-order packing, left child right behind its parent (:860-912).  leafFull (pruned trees): the complete
+// lists go behind all the pruned ones (fullRef counts from `fullBase`), in the same leaf order.
+void pack( BNode *n, uint64_t pos, uint64_t ref, uint64_t fullRef, rt_hip_kdnode *nodes, uint32_t *order, rt_hip_leaf_full *leafFull )
 {
 	if ( n->leaf )
 	{
@@ -440,17 +445,26 @@ void pack( BNode *n, uint64_t pos, uint64_t ref, rt_hip_kdnode *nodes, uint32_t 
 		nodes[pos].b = ( (uint32_t) n->prims.size() << 2 ) | 3u;
 		if ( !n->prims.empty() )
 			memcpy( order + ref, n->prims.data(), n->prims.size() * sizeof( uint32_t ) );
+		if ( leafFull )
+		{
+			leafFull[pos].first = (uint32_t) fullRef;
+			leafFull[pos].count = (uint32_t) n->full.size();
+			if ( !n->full.empty() )
+				memcpy( order + fullRef, n->full.data(), n->full.size() * sizeof( uint32_t ) );
+		}
 		delete n;
 		return;
 	}
 	uint64_t right = pos + 1 + n->l->nodes;
-	uint64_t rref = ref + n->l->refs;
+	uint64_t rref = ref + n->l->refs, rfull = fullRef + n->l->refsFull;
 	memcpy( &nodes[pos].a, &n->sep, 4 );
 	nodes[pos].b = ( (uint32_t) right << 2 ) | (uint32_t) n->axis;
+	if ( leafFull )
+		leafFull[pos].first = leafFull[pos].count = 0u;
 	BNode *l = n->l, *r = n->r;
 	delete n;
-	pack( l, pos + 1, ref, nodes, order );
-	pack( r, right, rref, nodes, order );
+	pack( l, pos + 1, ref, fullRef, nodes, order, leafFull );
+	pack( r, right, rref, rfull, nodes, order, leafFull );
 }
 
 void scene_box( const rt_vertex *verts, uint64_t n, rt_box &bbox )
@@ -647,21 +661,26 @@ extern "C" int rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangl
 		return rt_kdtree_build_flat_ex( verts, tris, vertexCount, trianglesCount, &plain, out );
 	}
 	totals( root );
-	if ( b.tooBig.load() || root->nodes >= ( 1ull << 30 ) || root->refs >= ( 1ull << 30 ) )
+	// (a pruned tree carries the complete lists behind the pruned ones - unless nothing was pruned)
+	const bool twoLists = b.pruneLeaves > 0.0f && b.dropped.load() != 0;
+	if ( b.tooBig.load() || root->nodes >= ( 1ull << 30 ) || root->refs + ( twoLists ? root->refsFull : 0 ) >= ( 1ull << 30 ) )
 	{
 		release_tree( root );
 		return 4;          // 30-bit links of the 8-byte node, or the memory a build may take
 	}
 	out->nNodes = root->nodes;
 	out->nRecs = root->refs;
+	out->nRecsFull = twoLists ? root->refsFull : 0;
 	out->nTris = nT;
 	out->depth = root->depth;
+	const uint64_t nAll = out->nRecs + out->nRecsFull;
 	out->nodes = (rt_hip_kdnode *) malloc( sizeof( rt_hip_kdnode ) * out->nNodes );
-	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( out->nRecs ? out->nRecs : 1 ) );
+	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( nAll ? nAll : 1 ) );
 	out->shade = (rt_hip_trishade *) malloc( sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
-	std::vector<uint32_t> order( out->nRecs ? out->nRecs : 1 );
-	pack( root, 0, 0, out->nodes, order.data() );
-	fill_records( verts, tris, nT, order.data(), out->nRecs, out->recs, out->shade, threads );
+	out->leafFull = twoLists ? (rt_hip_leaf_full *) malloc( sizeof( rt_hip_leaf_full ) * out->nNodes ) : nullptr;
+	std::vector<uint32_t> order( nAll ? nAll : 1 );
+	pack( root, 0, 0, out->nRecs, out->nodes, order.data(), out->leafFull );
+	fill_records( verts, tris, nT, order.data(), nAll, out->recs, out->shade, threads );
 	return 0;
 }
 
@@ -672,6 +691,7 @@ extern "C" void rt_kdtree_flat_release( rt_kdtree_flat *t )
 	free( t->nodes );
 	free( t->recs );
 	free( t->shade );
+	free( t->leafFull );
 	memset( t, 0, sizeof( *t ) );
 }
 

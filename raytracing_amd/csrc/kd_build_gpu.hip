@@ -706,6 +706,22 @@ __global__ __launch_bounds__( TB ) void k_prune_leaves( rt_hip_kdnode *nodes, ui
 		nodes[leaf].b = ( kept << 2 ) | 3u;
 }
 
+// where every leaf's complete list lies once a copy of the record array has been put behind it (`shift` records on)
+__global__ __launch_bounds__( TB ) void k_leaf_full( const rt_hip_kdnode *nodes, uint32_t nNodes, uint32_t shift, rt_hip_leaf_full *full )
+{
+	const uint32_t i = blockIdx.x * TB + threadIdx.x;
+	if ( i >= nNodes )
+		return;
+	const rt_hip_kdnode n = nodes[i];
+	rt_hip_leaf_full f = { 0u, 0u };
+	if ( ( n.b & 3u ) == 3u )
+	{
+		f.first = n.a + shift;
+		f.count = n.b >> 2;
+	}
+	full[i] = f;
+}
+
 inline unsigned grid_of( size_t n ) { return (unsigned) ( ( n + TB - 1 ) / TB ); }
 
 struct Scratch
@@ -789,6 +805,7 @@ extern "C" void rt_kdtree_device_release( rt_kdtree_device *t )
 	if ( t->nodes ) (void) hipFree( t->nodes );
 	if ( t->recs ) (void) hipFree( t->recs );
 	if ( t->shade ) (void) hipFree( t->shade );
+	if ( t->leafFull ) (void) hipFree( t->leafFull );
 	memset( t, 0, sizeof( *t ) );
 }
 
@@ -955,10 +972,19 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 
 	// output buffers (owned by the caller from here on)
 	const uint32_t nRecs = (uint32_t) leafRefs;
+	// pruned lists: the complete ones are kept behind them (read by rays parallel to an axis, see rt_kdtree.h)
+	const bool twoLists = opts->pruneLeaves > 0.0f && nRecs != 0u;
+	if ( twoLists && 2ull * nRecs >= ( 1ull << 30 ) )
+	{
+		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "pruned and complete leaf lists together exceed the 30-bit record index" );
+		return 4;
+	}
+	const size_t nAll = (size_t) nRecs * ( twoLists ? 2 : 1 );
 	{
 		hipError_t ea = hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * (size_t) nNodes );
-		if ( ea == hipSuccess ) ea = hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( (size_t) nRecs + 1 ) );
+		if ( ea == hipSuccess ) ea = hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( nAll + 1 ) );
 		if ( ea == hipSuccess ) ea = hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
+		if ( ea == hipSuccess && twoLists ) ea = hipMalloc( &out->leafFull, sizeof( rt_hip_leaf_full ) * (size_t) nNodes );
 		if ( ea != hipSuccess )
 		{
 			snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );
@@ -974,9 +1000,16 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 	if ( nT )
 		hipLaunchKernelGGL( k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
 			(rt_hip_trishade *) out->shade );
-	if ( opts->pruneLeaves > 0.0f && nRecs )
+	if ( twoLists )
+	{
+		rt_hip_trirec *recs = (rt_hip_trirec *) out->recs;
+		hipLaunchKernelGGL( k_leaf_full, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (const rt_hip_kdnode *) out->nodes, nNodes, nRecs,
+			(rt_hip_leaf_full *) out->leafFull );
+		GCHK( hipMemcpyAsync( recs + nRecs, recs, sizeof( rt_hip_trirec ) * (size_t) nRecs, hipMemcpyDeviceToDevice, s ) );
+		GCHK( hipMemsetAsync( recs + 2 * (size_t) nRecs, 0, sizeof( rt_hip_trirec ), s ) );       // the spare record at the very end
 		hipLaunchKernelGGL( k_prune_leaves, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (rt_hip_kdnode *) out->nodes, nNodes,
-			(rt_hip_trirec *) out->recs, dGeom, opts->pruneLeaves );
+			recs, dGeom, opts->pruneLeaves );
+	}
 	hipError_t e = hipGetLastError();
 	if ( e == hipSuccess ) e = hipStreamSynchronize( s );
 	if ( e != hipSuccess )
@@ -987,6 +1020,7 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 	}
 	out->nNodes = nNodes;
 	out->nRecs = nRecs;
+	out->nRecsFull = twoLists ? nRecs : 0;
 	out->nTris = nT;
 	out->depth = (int) rootDepth;
 	return 0;
@@ -1002,11 +1036,18 @@ extern "C" int rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_f
 	out->nTris = t->nTris;
 	out->bbox = t->bbox;
 	out->depth = t->depth;
+	const uint64_t nAll = t->nRecs + ( t->leafFull ? t->nRecsFull : 0 );
+	out->nRecsFull = nAll - t->nRecs;
 	out->nodes = (rt_hip_kdnode *) malloc( sizeof( rt_hip_kdnode ) * ( t->nNodes ? t->nNodes : 1 ) );
-	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( t->nRecs ? t->nRecs : 1 ) );
+	out->recs = (rt_hip_trirec *) malloc( sizeof( rt_hip_trirec ) * ( nAll ? nAll : 1 ) );
 	out->shade = (rt_hip_trishade *) malloc( sizeof( rt_hip_trishade ) * ( t->nTris ? t->nTris : 1 ) );
 	hipError_t e = hipMemcpy( out->nodes, t->nodes, sizeof( rt_hip_kdnode ) * t->nNodes, hipMemcpyDeviceToHost );
-	if ( e == hipSuccess && t->nRecs ) e = hipMemcpy( out->recs, t->recs, sizeof( rt_hip_trirec ) * t->nRecs, hipMemcpyDeviceToHost );
+	if ( e == hipSuccess && nAll ) e = hipMemcpy( out->recs, t->recs, sizeof( rt_hip_trirec ) * nAll, hipMemcpyDeviceToHost );
+	if ( e == hipSuccess && t->leafFull )
+	{
+		out->leafFull = (rt_hip_leaf_full *) malloc( sizeof( rt_hip_leaf_full ) * ( t->nNodes ? t->nNodes : 1 ) );
+		e = hipMemcpy( out->leafFull, t->leafFull, sizeof( rt_hip_leaf_full ) * t->nNodes, hipMemcpyDeviceToHost );
+	}
 	if ( e == hipSuccess && t->nTris ) e = hipMemcpy( out->shade, t->shade, sizeof( rt_hip_trishade ) * t->nTris, hipMemcpyDeviceToHost );
 	if ( e != hipSuccess )
 	{

@@ -97,7 +97,9 @@ struct rt_pipe_impl
 	std::vector<rt_material> mats;
 	rt_camera cam;
 	int maxDepth = MAX_DEPTH, maxPrims = MAX_PRIMS_IN_NODE, stackSize = STACK_SIZE;
-	int buildThreads = 0, treeCache = 0, pruneLeaves = 0;
+	// pruneLeaves: leaves list only the triangles that reach their cell (same frame, fewer triangle tests; the
+	// reference's complete lists are kept for the rays whose walk depends on them) - on unless switched off
+	int buildThreads = 0, treeCache = 0, pruneLeaves = 1;
 	int gpuBuild = 2;                 // 0 = host builder, 1 = GPU builder, 2 = GPU builder from GPU_BUILD_MIN triangles up
 	int bandH = 16, nParts = 1, part = 0;
 	bool matsDirty = true;
@@ -196,6 +198,8 @@ void rt_render_pipe_create( rt_render_pipe *pRp, int w, int h )
 	if ( !pRp->impl->hip )
 		die_hip( "cannot create the HIP context" );
 	pRp->impl->verts.hip = pRp->impl->tris.hip = pRp->impl->hip;
+	if ( rt_hip_set_param( pRp->impl->hip, RT_PARAM_PRUNE_LEAVES, pRp->impl->pruneLeaves ) )
+		die_hip( "rt_render_pipe_create" );
 	rt_init_buffers( pRp );
 	{
 		rt_camera &c = pRp->impl->cam;
@@ -474,10 +478,10 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 			fprintf( stderr, "rt: kd-tree build failed (%d)\n", rc );
 			exit( -3 );
 		}
-		if ( rt_hip_upload_tree( im->hip, t.nodes, t.nNodes, t.recs, t.nRecs, t.shade, t.nTris, &t.bbox, t.depth ) )
+		if ( rt_hip_upload_tree_lists( im->hip, t.nodes, t.nNodes, t.recs, t.nRecs, t.nRecsFull, t.leafFull, t.shade, t.nTris, &t.bbox, t.depth ) )
 			die_hip( "tree upload" );
 		im->lastInfo = t;
-		im->lastInfo.nodes = nullptr; im->lastInfo.recs = nullptr; im->lastInfo.shade = nullptr;
+		im->lastInfo.nodes = nullptr; im->lastInfo.recs = nullptr; im->lastInfo.shade = nullptr; im->lastInfo.leafFull = nullptr;
 		rt_kdtree_flat_release( &t );
 		im->haveTree = true;
 		im->geomHash = h;

@@ -125,6 +125,7 @@
 // with three frames in flight and at most 4 / 6 / 8 / 10 / 12 / 16 waves per CU and pass: 5.76 / 5.46 /
 // 5.38 / 5.40 / 5.50 / 5.76 ms (a 1/8 frame: 1.09 / 1.04 / 1.08 / 1.09 / 1.10 / 1.05 ms).  The default
 // serves the caller that renders one frame at a time; callers that keep frames in flight ask for 8.
+#define RT_MAX_LAUNCH_WAVES 20          // what fits a CU at five waves per SIMD
 #ifndef RT_OCC_CAP
 #define RT_OCC_CAP 16
 #endif
@@ -142,6 +143,9 @@ struct DevScene
 {
 	const uint2  *nodes;      // rt_hip_kdnode
 	const float4 *recs;       // rt_hip_trirec as 3 x float4
+	// pruned leaf lists only (else null): per node, (first record, count) of the leaf's COMPLETE list, which lies
+	// behind the pruned lists in `recs`; read by rays that are parallel to an axis (see axis_parallel)
+	const uint2  *leafFull;
 	const float4 *shade;      // rt_hip_trishade as 3 x float4
 	const rt_material *mats;
 	const float4 *spheres;    // (pos.xyz, rad)
@@ -1150,7 +1154,12 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
 	// the cooperative walk is the last thing a chunk does (nothing of the lane-per-ray
 	// walk stays live across it): rays parallel to an axis are finished first
-	const bool ownLane = coopLive == 0u || axis_parallel( r );
+	const bool axisPar = axis_parallel( r );
+	const bool ownLane = coopLive == 0u || axisPar;
+	// a ray parallel to an axis scans a leaf's COMPLETE list where the tree carries pruned ones: under the
+	// reference's NaN split distances (see axis_parallel) a hit can be confirmed by a leaf that lists the
+	// triangle without containing it
+	const bool viaFull = axisPar && S.leafFull != nullptr;
 	bool walked = atOnce;
 	while ( __ballot( live ) != 0ull )
 	{
@@ -1164,12 +1173,19 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 		walked = true;
 		PROF_INC( lock );
 		float lt = INFINITY;
-		uint32_t cnt = 0u;
+		uint32_t cnt = 0u, first = 0u;
 		PROF_T0( pd );
 		if ( live )
 		{
 			trav_descend<STATS>( S, src, inv, dest, st, t, tl );
+			first = t.n.x;
 			cnt = t.n.y >> 2;
+			if ( viaFull )
+			{
+				const uint2 f = S.leafFull[t.cur];
+				first = f.x;
+				cnt = f.y;
+			}
 		}
 		PROF_ADD( tDescend, pd );
 		PROF_T0( pl );
@@ -1178,7 +1194,7 @@ DEVI void nearest_wave( const DevScene &S, const Ray &r, const TriRay &R, const 
 			// Two records are kept in flight and take turns (no register copies); the
 			// array ends with one spare record, so the look-ahead load of the last
 			// triangle stays inside the buffer.
-			uint32_t i = t.n.x;
+			uint32_t i = first;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
 			for ( ;; )
@@ -1209,7 +1225,9 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 	uint32_t coopLive, uint32_t coopCap, bool atOnce PROF_ARG )
 {
 	const f3 src = r.src, inv = r.inv, dest = r.dest;
-	const bool ownLane = coopLive == 0u || axis_parallel( r );
+	const bool axisPar = axis_parallel( r );
+	const bool ownLane = coopLive == 0u || axisPar;
+	const bool viaFull = axisPar && S.leafFull != nullptr;      // (as in nearest_wave)
 	bool walked = atOnce;
 	while ( __ballot( live ) != 0ull )
 	{
@@ -1220,15 +1238,22 @@ DEVI void alpha_wave( const DevScene &S, const Ray &r, const TriRay &R, const St
 		}
 		walked = true;
 		PROF_INC( lock );
-		uint32_t cnt = 0u;
+		uint32_t cnt = 0u, first = 0u;
 		if ( live )
 		{
 			trav_descend<STATS>( S, src, inv, dest, st, t, tl );
+			first = t.n.x;
 			cnt = t.n.y >> 2;
+			if ( viaFull )
+			{
+				const uint2 f = S.leafFull[t.cur];
+				first = f.x;
+				cnt = f.y;
+			}
 		}
 		if ( live && cnt != 0u )
 		{
-			uint32_t i = t.n.x;
+			uint32_t i = first;
 			const uint32_t end = i + cnt;
 			Rec r0 = load_rec( S.recs, i );
 			for ( ;; )
@@ -2059,7 +2084,7 @@ struct rt_hip_ctx
 	hipStream_t own = nullptr, stream = nullptr;
 	DevScene S;
 	Work W;
-	DevBuf nodes, recs, shade, mats, spheres, sphereMat, lights;
+	DevBuf nodes, recs, shade, mats, spheres, sphereMat, lights, leafFull;
 	DevBuf ctr, rays, hitA, hitB, hitN, res, fac, shadow, stackPos, hitId, spill, frame;
 	DevBuf cam;                   // camera matrices of the frame being rendered (allocated with the context)
 	uint64_t nNodes = 0, nRecs = 0, nTris = 0, nMats = 0;
@@ -2209,7 +2234,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	{
 		if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &occ, k.f, RT_BLOCK, 0 ) != hipSuccess || occ < 1 )
 			occ = 1;
-		if ( occ * ( RT_BLOCK / 64 ) > 16 ) occ = 16 / ( RT_BLOCK / 64 );
+		if ( occ * ( RT_BLOCK / 64 ) > RT_MAX_LAUNCH_WAVES ) occ = RT_MAX_LAUNCH_WAVES / ( RT_BLOCK / 64 );
 		*k.dst = occ * c->numCU;
 		if ( k.occ ) *k.occ = occ;
 		if ( *k.dst > c->maxGrid ) c->maxGrid = *k.dst;
@@ -2222,7 +2247,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	if ( const char *v = getenv( "RT_COOP_SHADOW" ) ) c->coopShadow = atoi( v );
 	if ( const char *v = getenv( "RT_COOP_CLOSEST" ) ) c->coopClosest = atoi( v );
 	if ( const char *v = getenv( "RT_BIG_FRAME" ) ) c->bigFrame = (uint32_t) atoll( v );
-	if ( const char *v = getenv( "RT_LAUNCH_WAVES" ) ) if ( atoi( v ) >= 1 && atoi( v ) <= 16 ) c->launchWaves = atoi( v );
+	if ( const char *v = getenv( "RT_LAUNCH_WAVES" ) ) if ( atoi( v ) >= 1 && atoi( v ) <= RT_MAX_LAUNCH_WAVES ) c->launchWaves = atoi( v );
 	// a streaming pass gains nothing from more than a few waves per SIMD
 	if ( c->gridLight > RT_STREAM_OCC * c->numCU ) c->gridLight = RT_STREAM_OCC * c->numCU;
 
@@ -2256,7 +2281,7 @@ void rt_hip_destroy( rt_hip_ctx *c )
 		if ( c->evHit[k] ) (void) hipEventDestroy( c->evHit[k] );
 		if ( c->evLit[k] ) (void) hipEventDestroy( c->evLit[k] );
 	}
-	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights, &c->cam,
+	DevBuf *all[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights, &c->cam, &c->leafFull,
 		&c->ctr, &c->rays, &c->hitA, &c->hitB, &c->hitN, &c->res, &c->fac, &c->shadow, &c->stackPos, &c->hitId, &c->spill, &c->frame };
 	for ( DevBuf *b : all )
 		if ( b->p ) (void) hipFree( b->p );
@@ -2294,11 +2319,20 @@ int rt_hip_set_stream( rt_hip_ctx *c, void *s )
 int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes, const rt_hip_trirec *recs,
 	uint64_t nRecs, const rt_hip_trishade *shade, uint64_t nTris, const rt_box *bbox, int depth )
 {
-	if ( !c || !nodes || !bbox || nNodes == 0 || ( nRecs && !recs ) || ( nTris && !shade ) )
+	return rt_hip_upload_tree_lists( c, nodes, nNodes, recs, nRecs, 0, nullptr, shade, nTris, bbox, depth );
+}
+
+int rt_hip_upload_tree_lists( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNodes, const rt_hip_trirec *recs,
+	uint64_t nRecs, uint64_t nRecsFull, const rt_hip_leaf_full *leafFull, const rt_hip_trishade *shade, uint64_t nTris,
+	const rt_box *bbox, int depth )
+{
+	if ( !c || !nodes || !bbox || nNodes == 0 || ( nRecs && !recs ) || ( nTris && !shade ) || ( nRecsFull && !leafFull ) )
 		return fail( "rt_hip_upload_tree: bad arguments" );
+	if ( !leafFull ) nRecsFull = 0;
 	if ( depth > RT_HIP_MAX_TREE_DEPTH )
 		return fail( "rt_hip_upload_tree: tree depth %d exceeds the traversal stack (%d)", depth, RT_HIP_MAX_TREE_DEPTH );
-	if ( nNodes >= ( 1ull << 30 ) || nRecs >= ( 1ull << 30 ) || nTris >= ( 1ull << 31 ) )
+	const uint64_t nAll = nRecs + nRecsFull;
+	if ( nNodes >= ( 1ull << 30 ) || nAll >= ( 1ull << 30 ) || nTris >= ( 1ull << 31 ) )
 		return fail( "rt_hip_upload_tree: tree too large for 32-bit node links" );
 	// host-side shape check: every link and record range must stay inside the
 	// arrays (an out-of-range link would fault the GPU), and children must
@@ -2313,6 +2347,8 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 		{
 			if ( (uint64_t) nodes[i].a + ( b >> 2 ) > nRecs )
 				return fail( "rt_hip_upload_tree: leaf %llu references records beyond %llu", (unsigned long long) i, (unsigned long long) nRecs );
+			if ( leafFull && (uint64_t) leafFull[i].first + leafFull[i].count > nAll )
+				return fail( "rt_hip_upload_tree: the complete list of leaf %llu lies beyond the %llu records", (unsigned long long) i, (unsigned long long) nAll );
 			continue;
 		}
 		const uint64_t right = b >> 2;
@@ -2325,7 +2361,7 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 		if ( level[right] < l ) level[right] = l;
 	}
 	uint64_t maxMat = 0;
-	for ( uint64_t i = 0; i < nRecs; ++i )
+	for ( uint64_t i = 0; i < nAll; ++i )
 	{
 		if ( recs[i].tri >= nTris )
 			return fail( "rt_hip_upload_tree: record %llu references triangle %u of %llu", (unsigned long long) i, recs[i].tri, (unsigned long long) nTris );
@@ -2338,14 +2374,16 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *nodes, uint64_t nNod
 	scene_changed( c );
 	if ( upload( c, c->nodes, nodes, nNodes * sizeof( rt_hip_kdnode ) ) ) return 1;
 	// one spare record: the leaf loop loads one record ahead
-	if ( ensure( c, c->recs, ( nRecs + 1 ) * sizeof( rt_hip_trirec ) ) ) return 1;
-	HIPCHK( hipMemsetAsync( (char *) c->recs.p + nRecs * sizeof( rt_hip_trirec ), 0, sizeof( rt_hip_trirec ), c->stream ) );
-	if ( upload( c, c->recs, recs, nRecs * sizeof( rt_hip_trirec ) ) ) return 1;
+	if ( ensure( c, c->recs, ( nAll + 1 ) * sizeof( rt_hip_trirec ) ) ) return 1;
+	HIPCHK( hipMemsetAsync( (char *) c->recs.p + nAll * sizeof( rt_hip_trirec ), 0, sizeof( rt_hip_trirec ), c->stream ) );
+	if ( upload( c, c->recs, recs, nAll * sizeof( rt_hip_trirec ) ) ) return 1;
 	if ( upload( c, c->shade, shade, nTris * sizeof( rt_hip_trishade ) ) ) return 1;
+	if ( leafFull && upload( c, c->leafFull, leafFull, nNodes * sizeof( rt_hip_leaf_full ) ) ) return 1;
 	c->nNodes = nNodes; c->nRecs = nRecs; c->nTris = nTris; c->treeDepth = depth;
 	c->S.nodes = (const uint2 *) c->nodes.p;
 	c->S.recs = (const float4 *) c->recs.p;
 	c->S.shade = (const float4 *) c->shade.p;
+	c->S.leafFull = leafFull ? (const uint2 *) c->leafFull.p : nullptr;
 	c->S.bbC[0] = bbox->center.x; c->S.bbC[1] = bbox->center.y; c->S.bbC[2] = bbox->center.z;
 	c->S.bbE[0] = bbox->extents.x; c->S.bbE[1] = bbox->extents.y; c->S.bbE[2] = bbox->extents.z;
 	return 0;
@@ -2365,7 +2403,7 @@ int rt_hip_adopt_tree( rt_hip_ctx *c, rt_kdtree_device *t )
 	scene_changed( c );
 	DevBuf *dst[3] = { &c->nodes, &c->recs, &c->shade };
 	void *src[3] = { t->nodes, t->recs, t->shade };
-	const size_t bytes[3] = { t->nNodes * sizeof( rt_hip_kdnode ), ( t->nRecs + 1 ) * sizeof( rt_hip_trirec ),
+	const size_t bytes[3] = { t->nNodes * sizeof( rt_hip_kdnode ), ( t->nRecs + ( t->leafFull ? t->nRecsFull : 0 ) + 1 ) * sizeof( rt_hip_trirec ),
 		( t->nTris ? t->nTris : 1 ) * sizeof( rt_hip_trishade ) };
 	for ( int i = 0; i < 3; ++i )
 	{
@@ -2373,6 +2411,10 @@ int rt_hip_adopt_tree( rt_hip_ctx *c, rt_kdtree_device *t )
 		dst[i]->p = src[i];
 		dst[i]->cap = bytes[i];
 	}
+	if ( c->leafFull.p ) HIPCHK( hipFree( c->leafFull.p ) );
+	c->leafFull.p = t->leafFull;
+	c->leafFull.cap = t->leafFull ? t->nNodes * sizeof( rt_hip_leaf_full ) : 0;
+	c->S.leafFull = (const uint2 *) c->leafFull.p;
 	c->maxMatTree = t->maxMaterial;
 	c->nNodes = t->nNodes; c->nRecs = t->nRecs; c->nTris = t->nTris; c->treeDepth = t->depth;
 	c->S.nodes = (const uint2 *) c->nodes.p;
@@ -2418,10 +2460,10 @@ int rt_hip_share_scene( rt_hip_ctx *c, const rt_hip_ctx *from )
 	HIPCHK( hipSetDevice( c->device ) );
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	// own copies, if any, are released: the pointers below replace them
-	DevBuf *own[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights };
+	DevBuf *own[] = { &c->nodes, &c->recs, &c->shade, &c->mats, &c->spheres, &c->sphereMat, &c->lights, &c->leafFull };
 	for ( DevBuf *b : own )
 		if ( b->p ) { HIPCHK( hipFree( b->p ) ); b->p = nullptr; b->cap = 0; }
-	c->S.nodes = from->S.nodes; c->S.recs = from->S.recs; c->S.shade = from->S.shade;
+	c->S.nodes = from->S.nodes; c->S.recs = from->S.recs; c->S.shade = from->S.shade; c->S.leafFull = from->S.leafFull;
 	c->S.mats = from->S.mats; c->S.spheres = from->S.spheres; c->S.sphereMat = from->S.sphereMat; c->S.lights = from->S.lights;
 	c->S.nSpheres = from->S.nSpheres; c->S.nLights = from->S.nLights; c->S.alphaMonotone = from->S.alphaMonotone;
 	memcpy( c->S.bbC, from->S.bbC, sizeof( c->S.bbC ) );
@@ -2564,7 +2606,7 @@ int rt_hip_set_param( rt_hip_ctx *c, int key, int value )
 	}
 	if ( key == RT_PARAM_LAUNCH_WAVES )
 	{
-		if ( value < 1 || value > 16 ) return fail( "RT_PARAM_LAUNCH_WAVES must be 1..16" );
+		if ( value < 1 || value > RT_MAX_LAUNCH_WAVES ) return fail( "RT_PARAM_LAUNCH_WAVES must be 1..%d", RT_MAX_LAUNCH_WAVES );
 		c->launchWaves = value;
 		return 0;
 	}

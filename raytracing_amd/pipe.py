@@ -22,6 +22,7 @@ RT_HIP_STATS, RT_HIP_HITIDS, RT_HIP_TIMING = 1, 2, 4
  RT_PARAM_COOP_LIVE, RT_PARAM_COOP_STACK, RT_PARAM_LAUNCH_WAVES, RT_PARAM_PRUNE_LEAVES) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 kdnode = np.dtype([("a", "<u4"), ("b", "<u4")])
+leaf_full = np.dtype([("first", "<u4"), ("count", "<u4")])
 trirec = np.dtype([("nv0x", "<f4"), ("e1x", "<f4"), ("nv0y", "<f4"), ("e1y", "<f4"),
                    ("nv0z", "<f4"), ("e1z", "<f4"), ("e2x", "<f4"), ("e2y", "<f4"),
                    ("e2z", "<f4"), ("tri", "<u4"), ("mat", "<u4"), ("_pad", "<u4")])
@@ -103,8 +104,11 @@ class FlatTree:
     def __init__(self, struct):
         self._s = struct
         self.nodes = _view(struct.nodes, struct.nNodes, kdnode)
-        self.recs = _view(struct.recs, struct.nRecs, trirec)
+        self.recs = _view(struct.recs, struct.nRecs, trirec)                  # the lists the nodes point to
         self.shade = _view(struct.shade, struct.nTris, trishade)
+        # pruned leaf lists only: every leaf's complete list, stored behind `recs`, and where it lies per node
+        self.leaf_full = _view(struct.leafFull, struct.nNodes, leaf_full) if struct.leafFull else None
+        self.recs_all = _view(struct.recs, struct.nRecs + (struct.nRecsFull if struct.leafFull else 0), trirec)
         self.bbox = np.frombuffer(bytes(struct.bbox), T.box)[0]
         self.depth = struct.depth
 
@@ -157,7 +161,7 @@ class FlatTree:
         if self._s is not None:
             lib().rt_kdtree_flat_release(C.byref(self._s))
             self._s = None
-            self.nodes = self.recs = self.shade = None
+            self.nodes = self.recs = self.shade = self.leaf_full = self.recs_all = None
 
     def __del__(self):
         try:
@@ -192,11 +196,20 @@ class HipRenderer:
 
     # -- scene ----------------------------------------------------------------
     def upload_tree(self, tree):
-        check(self._L.rt_hip_upload_tree(self._c, _p(tree.nodes), C.c_uint64(len(tree.nodes)),
-                                         _p(tree.recs), C.c_uint64(len(tree.recs)),
-                                         _p(tree.shade), C.c_uint64(len(tree.shade)),
-                                         _p(np.array([tree.bbox], T.box)), C.c_int(tree.depth)),
-              "rt_hip_upload_tree")
+        full = getattr(tree, "leaf_full", None)
+        if full is None:
+            check(self._L.rt_hip_upload_tree(self._c, _p(tree.nodes), C.c_uint64(len(tree.nodes)),
+                                             _p(tree.recs), C.c_uint64(len(tree.recs)),
+                                             _p(tree.shade), C.c_uint64(len(tree.shade)),
+                                             _p(np.array([tree.bbox], T.box)), C.c_int(tree.depth)),
+                  "rt_hip_upload_tree")
+            return
+        check(self._L.rt_hip_upload_tree_lists(self._c, _p(tree.nodes), C.c_uint64(len(tree.nodes)),
+                                               _p(tree.recs_all), C.c_uint64(len(tree.recs)),
+                                               C.c_uint64(len(tree.recs_all) - len(tree.recs)), _p(full),
+                                               _p(tree.shade), C.c_uint64(len(tree.shade)),
+                                               _p(np.array([tree.bbox], T.box)), C.c_int(tree.depth)),
+              "rt_hip_upload_tree_lists")
 
     def upload_materials(self, mats):
         mats = np.ascontiguousarray(mats, T.material)

@@ -36,6 +36,13 @@ int rt_hip_upload_tree( rt_hip_ctx *c, const rt_hip_kdnode *n, uint64_t nn, cons
 	c->sum += touch( n, nn * sizeof( *n ) ) + touch( r, nr * sizeof( *r ) ) + touch( s, nt * sizeof( *s ) ) + touch( b, sizeof( *b ) );
 	return 0;
 }
+int rt_hip_upload_tree_lists( rt_hip_ctx *c, const rt_hip_kdnode *n, uint64_t nn, const rt_hip_trirec *r, uint64_t nr, uint64_t nf,
+	const rt_hip_leaf_full *lf, const rt_hip_trishade *s, uint64_t nt, const rt_box *b, int )
+{
+	c->sum += touch( n, nn * sizeof( *n ) ) + touch( r, ( nr + ( lf ? nf : 0 ) ) * sizeof( *r ) ) + touch( s, nt * sizeof( *s ) ) + touch( b, sizeof( *b ) );
+	if ( lf ) c->sum += touch( lf, nn * sizeof( *lf ) );
+	return 0;
+}
 int rt_hip_adopt_tree( rt_hip_ctx *, struct _rt_kdtree_device * ) { return 1; }
 int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *v, const rt_triangle *t, uint64_t nv, uint64_t nt, int, int )
 {

@@ -162,8 +162,12 @@ def test_device_builder_prunes_leaves_like_the_host_builder(name):
     for k in ("isLast", "leftNode", "rightNode", "sep", "axis"):
         assert np.array_equal(pn[k], gn[k]), k
     assert np.array_equal(np.where(pn["isLast"] != 0, pn["prims"], 0), np.where(gn["isLast"] != 0, gn["prims"], 0))
+    # the complete lists are kept behind the pruned ones (for rays parallel to an axis)
+    assert got.leaf_full is not None and len(got.recs_all) == 2 * len(plain.recs)
     kept_h = kept_g = differ = 0
     for i, full in lp.items():
+        f, m = int(got.leaf_full["first"][i]), int(got.leaf_full["count"][i])
+        assert (f, m) == (len(plain.recs) + int(pn["prims"][i]), len(full)) and got.recs_all["tri"][f:f + m].tolist() == full, i
         it = iter(full)
         assert all(x in it for x in lg[i]), i                                     # sub-sequence, order kept
         kept_h += len(lh[i])

@@ -572,7 +572,7 @@ def test_overlapped_and_in_order_schedules_give_the_same_frame():
 
 def test_waves_per_pass_do_not_change_the_frame():
     """RT_PARAM_LAUNCH_WAVES only sizes the persistent grids of the traversal passes (how many waves of a CU
-    one pass occupies); values outside 1..16 are refused."""
+    one pass occupies); values outside 1..20 are refused."""
     from raytracing_amd._lib import RtError
     from raytracing_amd.pipe import RT_PARAM_LAUNCH_WAVES
     sc, depth, prims = IMG["sphere16k_glass"]
@@ -581,13 +581,13 @@ def test_waves_per_pass_do_not_change_the_frame():
     r = HipRenderer(0)
     r.load_scene(sc, tree)
     out = []
-    for waves in (16, 1, 6, 8, 16):
+    for waves in (16, 1, 6, 8, 20, 16):
         r.set_param(RT_PARAM_LAUNCH_WAVES, waves)
         r.render(RT_HIP_HITIDS | RT_HIP_STATS)
         st = r.stats()
         # (node visits are not compared: how many leaves the cooperative walk scans ahead depends on how a list is dealt out)
         out.append((r.read_frame().copy(), r.read_hit_ids().copy(), st["raysClosest"], st["raysShadow"], st["hits"]))
-    for bad in (0, 17, -3):
+    for bad in (0, 21, -3):
         with pytest.raises(RtError, match="RT_PARAM_LAUNCH_WAVES"):
             r.set_param(RT_PARAM_LAUNCH_WAVES, bad)
     r.close()
@@ -923,14 +923,17 @@ def test_8k_frame_sampled_against_oracle_and_size_limits():
     r.close()
 
 
+@pytest.mark.parametrize("prune", [0.0, 1e-5])
 @pytest.mark.parametrize("seed", [0, 1, 3, 10, 11])
-def test_rays_parallel_to_an_axis_with_the_origin_in_a_split_plane(seed):
+def test_rays_parallel_to_an_axis_with_the_origin_in_a_split_plane(seed, prune):
     """Odd image sizes give the middle row / column a direction component of
     exactly 0, integer geometry symmetric about the camera puts split planes
     through the origin: the split distance 0 * inf is a NaN, which the
     reference turns into 'both children' and into an exit distance that
     rejects every hit.  Such rays must be walked literally (these seeds are
-    the ones a pruned walk got wrong)."""
+    the ones a walk with shortcuts got wrong) - and over the reference's leaf
+    lists: with pruned lists (prune > 0) they scan the complete lists kept
+    behind the pruned ones, the oracle walks the reference's tree."""
     rng = np.random.RandomState(seed)
     w, h = int(rng.choice([65, 97, 33])), int(rng.choice([49, 71, 33]))
     sc = scenes.Scene(f"axis{seed}", w, h, scenes.make_camera(w, h, hv=float(rng.choice([0.5, 0.9]))))
@@ -948,12 +951,47 @@ def test_rays_parallel_to_an_axis_with_the_origin_in_a_split_plane(seed):
     sc.lights += [scenes.make_light((0.0, -10.0, 0.0), 40.0), scenes.make_light((5.0, 0.0, 0.0), 40.0)]
     sc.stack_size = 6
     depth, prims = int(rng.choice([10, 20])), int(rng.choice([2, 7]))
-    img, ids, st, tree = hip_render(sc, depth, prims)
+    img, ids, st, tree = hip_render(sc, depth, prims, prune=prune)
+    if prune:
+        # (where the reference's partition dropped a triangle that lies in a split plane the builder refuses to prune)
+        assert tree.leaf_full is None or len(tree.recs_all) > len(tree.recs)
+        tree.release()
+        tree = FlatTree.build(v, t, depth, prims)
     nodes, idx = tree.expand()
     assert np.frombuffer(nodes["sep"][:1].tobytes(), np.float32)[0] == 0.0
     oimg, oid, ost = orc.raytrace(sc, tree.bbox, nodes, idx)
     assert np.array_equal(ids, oid) and np.array_equal(img, oimg)
     assert (st["raysClosest"], st["raysShadow"]) == (ost["raysClosest"], ost["raysShadow"])
+
+
+def test_pruned_lists_are_exact_for_the_reference_nan_walks():
+    """Scene 7383 of the randomised sweep: the camera in the centre of integer geometry, so that rays of the middle
+    column start in split planes with a direction component of exactly zero.  Under the NaN split distances the
+    reference computes there, whole sub-trees cannot confirm a hit, and it is confirmed instead by a leaf that lists
+    the triangle without containing it.  With pruned lists alone the frame differs; with the complete lists kept
+    behind them (which the rays parallel to an axis scan) it is the oracle's frame on the reference's tree."""
+    from tests.helpers import stress_scene
+    sc, depth, prims, _, kind, n = stress_scene(7383)
+    assert (kind, n) == (3, 400)
+    v, t = sc.flatten()
+    plain = FlatTree.build(v, t, depth, prims)
+    nodes, idx = plain.expand()
+    oimg, oid, _ = orc.raytrace(sc, plain.bbox, nodes, idx)
+    plain.release()
+    tree = FlatTree.build(v, t, depth, prims, prune_leaves=1e-5)
+    assert tree.leaf_full is not None
+    frames = []
+    for lists in ("both", "pruned only"):
+        if lists == "pruned only":
+            tree.leaf_full = None                  # (upload_tree then hands over the pruned lists alone)
+        r = HipRenderer(0)
+        r.load_scene(sc, tree)
+        r.render(RT_HIP_HITIDS)
+        frames.append((r.read_frame().copy(), r.read_hit_ids().copy()))
+        r.close()
+    assert np.array_equal(frames[0][0], oimg) and np.array_equal(frames[0][1], oid)
+    assert not np.array_equal(frames[1][1], oid)          # the case is a real one
+    tree.release()
 
 
 def test_a_frame_can_be_captured_in_a_hip_graph_and_replayed():

@@ -3,7 +3,9 @@ helper; the committed tests hold a fixed subset): random triangle soups with
 spheres and lights, random materials (opaque / transparent / reflective),
 random tree limits, ray budgets, overlap on and off, band splits.
 With RT_PRUNE=<margin> the GPU renders the tree with pruned leaf lists
-(pruneLeaves of the host builder) while the oracle walks the reference's.
+(pruneLeaves of the host builder) while the oracle walks the reference's;
+RT_PRUNE_ONLY=1 additionally withholds the complete lists that rays parallel
+to an axis scan, which shows the scenes that need them.
 Usage: python tools/stress_parity.py [first_seed] [count]"""
 import os
 import sys
@@ -13,50 +15,16 @@ from raytracing_amd import scenes
 from raytracing_amd import types as T
 from raytracing_amd.dist import band_rows
 from raytracing_amd.pipe import (RT_HIP_HITIDS, RT_HIP_STATS, RT_PARAM_OVERLAP, RT_PARAM_STACK_SIZE, FlatTree, HipRenderer)
-from tests.helpers import random_soup
+from tests.helpers import stress_scene
 from raytracing_amd._lib import RtError  # noqa: F401
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for seed in range(first, first + count):
-    rng = np.random.RandomState(seed)
-    w, h = int(rng.choice([64, 96, 130, 65, 33])), int(rng.choice([48, 70, 101, 49]))
-    sc = scenes.Scene(f"stress{seed}", w, h, scenes.make_camera(w, h, hv=float(rng.uniform(0.3, 0.9))))
-    n = int(rng.choice([1, 30, 400, 3000]))
-    v, t = random_soup(n, seed, extent=float(rng.uniform(5, 30)), size=float(rng.uniform(1, 8)))
-    kind = int(rng.randint(6))
-    if kind == 1:                                   # integer coordinates: exact ties, hits on edges and vertices
-        for a in "xyz":
-            v["pos"][a] = np.round(v["pos"][a])
-    elif kind == 2 and n > 4:                       # zero-area and repeated triangles
-        t["pV1"][::3] = t["pV0"][::3]
-        t[n // 2:] = t[:n - n // 2]
-    elif kind == 3:                                 # camera inside integer geometry centred on it
-        for a in "xyz":
-            v["pos"][a] = np.round(v["pos"][a] - (60.0 if a == "z" else 0.0))
-    elif kind == 4:                                 # everything in one plane facing the camera
-        v["pos"]["z"] = 40.0
-    sc.meshes.append(scenes.Mesh(v, t, 0))
-    sc.flatten = lambda v=v, t=t: (v, t)        # keep the per-triangle materials 0..2
-    for m in range(3):
-        alpha = float(rng.choice([1.0, 1.0, 0.6, 0.3, 0.0]))
-        refl = float(rng.choice([0.0, 0.4, 0.8]))
-        sc.materials[m] = T.make_material((alpha, *rng.uniform(0.2, 1.0, 3)), (0.0, 0.05, 0.05, 0.05), (0.0, 0.6, 0.6, 0.6),
-                                          (float(rng.uniform(2, 30)), 0.4, 0.4, 0.4), (0.0, refl, refl, refl),
-                                          float(rng.choice([0.0, 0.02, 0.2])), float(rng.choice([1.0, 1.33, 1.6])))
-    sc.spheres += [scenes.make_sphere(rng.uniform(-20, 20, 3) + (0, 0, 60), float(rng.uniform(2, 9)), int(rng.randint(3)))
-                   for _ in range(int(rng.randint(0, 4)))]
-    if kind == 5:                                   # the camera sits inside a sphere (hits from the inside, side = -1)
-        sc.spheres.append(scenes.make_sphere((1.0, -2.0, 10.0), float(rng.uniform(60, 140)), int(rng.randint(3))))
-    sc.lights += [scenes.make_light(rng.uniform(-40, 40, 3), float(rng.uniform(30, 120))) for _ in range(int(rng.randint(0, 4)))]
-    sc.stack_size = int(rng.randint(1, 9))
-    depth, prims = int(rng.choice([0, 4, 10, 20, 30])), int(rng.choice([1, 3, 7, 12, 40]))
+    sc, depth, prims, rng, kind, n = stress_scene(seed)
+    w, h = sc.w, sc.h
     vv, tt = sc.flatten()
-    if n >= 3000:
-        depth = min(depth, 20 if prims > 3 else 16)      # overlapping triangles cannot be separated: references double per level
-    elif n >= 400 and prims <= 3:
-        depth = min(depth, 20)
     try:
         tree = FlatTree.build(vv, tt, depth, prims)
     except Exception as e:          # tree beyond the 30-bit links: a legitimate refusal
@@ -67,6 +35,8 @@ for seed in range(first, first + count):
     if float(os.environ.get("RT_PRUNE", "0")) > 0:
         tree.release()
         tree = FlatTree.build(vv, tt, depth, prims, prune_leaves=float(os.environ["RT_PRUNE"]))
+        if os.environ.get("RT_PRUNE_ONLY"):       # (without the complete lists behind the pruned ones: shows which scenes need them)
+            tree.leaf_full = None
     r = HipRenderer(0)
     r.load_scene(sc, tree)
     r.set_param(RT_PARAM_STACK_SIZE, sc.stack_size)
