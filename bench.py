@@ -715,13 +715,14 @@ def main():
     for sl in reversed(all_slots):               # (the first one owns the scene the others read)
         sl.r.close()
 
-    # ---- the other two single-GPU workloads, 5 steps each (so that whoever times this command times them as well);
+    # ---- the other two single-GPU workloads, a few steps each (so that whoever times this command times them as well);
     # after this workload's contexts have been closed: their streams would share hardware queues with the new ones
     other = None
     if world == 1 and args.workload == "config3" and not args.timed_only and not args.no_other_configs:
-        other = {"config2": side_workload("config2", local_dev, dev, 22, args.leaf, args.prune_leaves, 5),
+        # (a 1080p frame takes 0.8 ms: 5 steps would time little more than the filling and draining of four contexts)
+        other = {"config2": side_workload("config2", local_dev, dev, 22, args.leaf, args.prune_leaves, 20),
                  # (the fly-through renders the geometry of this workload: same trees)
-                 "config5": side_workload("config5", local_dev, dev, args.depth, args.leaf, args.prune_leaves, 5, tree=tree, plain=plain)}
+                 "config5": side_workload("config5", local_dev, dev, args.depth, args.leaf, args.prune_leaves, 8, tree=tree, plain=plain)}
         if not all(o["frames_verified"] for o in other.values()):
             raise SystemExit("a frame of one of the other workloads differs from the frame rendered on its own: "
                              + json.dumps({k: o["frames_verified"] for k, o in other.items()}))

@@ -7,7 +7,7 @@
 #   pmc_serial/                the same with every pass alone on the chip (RT_OVERLAP=0)
 # Usage: tools/profile_round.sh <tag> ; then, here: python tools/refresh_profiles.py <tag> <round, e.g. r02>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 export PYTHONPATH=. TMPDIR=/tmp
 mkdir -p $OUT

@@ -54,6 +54,11 @@ path = f"profiles/{rnd}_counters.json"
 tr = json.load(open(path)) if os.path.exists(path) else {}
 tr[key + "/overlap"] = summary(src + "/pmc", f"profiles/{rnd}_pmc_summary.csv")
 tr[key + "/serial"] = summary(src + "/pmc_serial", f"profiles/{rnd}_pmc_summary_serial.csv")
+if os.path.isdir(src + "/pmc_config5"):
+    tr[key.replace("config3", "config5") + "/overlap"] = summary(src + "/pmc_config5", f"profiles/{rnd}_pmc_summary_config5.csv")
+for w in ("config2", "config5"):
+    if os.path.exists(f"{src}/bench_{w}.json"):
+        shutil.copy(f"{src}/bench_{w}.json", f"profiles/{rnd}_bench_{w}.json")
 json.dump(tr, open(path, "w"), indent=1)
 b = json.load(open(f"profiles/{rnd}_bench_config3.json"))
 print({k: b[k] for k in ("value", "ms_per_step", "kernel_ms_per_frame_rank0", "kernel_wall_ms_per_frame_rank0")})
