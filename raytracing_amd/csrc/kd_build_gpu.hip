@@ -19,12 +19,10 @@
 // (tests/test_kdtree_gpu.py).  The host drives the level loop and reads three
 // totals per level to size the next one.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <vector>
 
 #include "rt_kdtree.h"
 
@@ -38,6 +36,12 @@ constexpr int TB = 256;
 	return 10; } } while ( 0 )
 
 thread_local char g_gpu_build_err[512] = "";
+
+// a launch that is refused (grid, block or LDS size) says so at once, by name
+#define LAUNCH_OR( cleanup, kernel, ... ) do { hipLaunchKernelGGL( kernel, __VA_ARGS__ ); hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { \
+	snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "launch of %s failed: %s (%s:%d)", #kernel, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
+	cleanup; return 10; } } while ( 0 )
+#define LAUNCH( ... ) LAUNCH_OR( (void) 0, __VA_ARGS__ )
 
 // device buffer that grows (contents are NOT kept unless keep > 0)
 struct DVec
@@ -166,10 +170,8 @@ __global__ __launch_bounds__( TB ) void k_box_partial( const rt_vertex *verts, u
 	}
 }
 
-// one wave: folds the partial boxes, applies the rules for vertex 0 and the
-// margin, and fills the root's entry of the level table
-__global__ __launch_bounds__( 64 ) void k_box_final( const rt_vertex *verts, uint64_t nV, const float *part, int nPart, uint32_t nT,
-	GeomInfo *info, float *rootBox, uint32_t *rootStart, uint32_t *rootCount )
+// one wave: folds the partial boxes, applies the rules for vertex 0 and the margin
+__global__ __launch_bounds__( 64 ) void k_box_final( const rt_vertex *verts, uint64_t nV, const float *part, int nPart, GeomInfo *info )
 {
 	const float inf = __builtin_huge_valf();
 	float mn[3] = { inf, inf, inf }, mx[3] = { -inf, -inf, -inf };
@@ -205,11 +207,7 @@ __global__ __launch_bounds__( 64 ) void k_box_final( const rt_vertex *verts, uin
 		const float c = ( lo + hi ) * 0.5f, e = ( hi - lo ) * 0.5f;
 		info->box[a] = c;
 		info->box[3 + a] = e;
-		rootBox[a] = c;
-		rootBox[3 + a] = e;
 	}
-	*rootStart = 0u;
-	*rootCount = nT;
 }
 
 __global__ __launch_bounds__( TB ) void k_iota( uint32_t *refs, uint32_t *refNode, uint32_t n )
@@ -222,64 +220,99 @@ __global__ __launch_bounds__( TB ) void k_iota( uint32_t *refs, uint32_t *refNod
 	}
 }
 
-// ---- level tables (one entry per node of the level) ----------------------
-struct LevelTab
+// ---- the level loop's state lives in device memory --------------------------
+// The host enqueues every level up to the depth limit without looking at a count:
+// launches have fixed grids, every kernel reads its level's counts from here and
+// returns when there is nothing to do (levels below the deepest one, or a work
+// buffer turned out too small: then the host grows it and builds again).
+struct LevelState
 {
+	uint32_t nodes, refs;       // nodes of this depth, triangle references held by them
+	uint32_t nodeBase;          // nodes of all levels above (= level-order number of this level's first node)
+	uint32_t leafBase;          // references in leaves of all levels above
+};
+
+enum : uint32_t { OVF_NONE = 0u, OVF_REFS = 1u, OVF_LEVEL_NODES = 2u, OVF_NODES = 3u, OVF_LEAF = 4u, OVF_LINKS = 5u };
+
+struct BuildState
+{
+	LevelState lv[RT_HIP_MAX_TREE_DEPTH + 2];
+	uint32_t overflow;          // OVF_*
+	uint32_t need;              // the count that did not fit
+	uint32_t nLevels, nodesTotal, leafRefs;     // written by the level that splits nothing
+};
+
+struct Caps { uint32_t refs, levelNodes, nodesTotal, leaf; };
+
+// ---- node table of one level (one entry per node of the level) ---------------
+enum : uint32_t { K_SPLIT = 1u, K_SORTED = 8u, K_DONE = 16u };     // (bits 1-2: split axis)
+
+struct NodeTab
+{
+	uint4 *excl;           // over the nodes before this one: x inner nodes, y references handed to children, z references in leaves, w references handed to left children
 	float *box;            // [6 * n]: centre xyz, half extent xyz
 	uint32_t *start, *count;
-};
-
-struct NodeWork            // per node of the current level
-{
-	uint32_t *split;       // 1 = inner node
-	uint32_t *axis;
-	uint32_t *sorted;      // candidate planes ascending (always, except for NaN / inverted boxes)
-	float *mn, *delta;
-	uint32_t *hist;        // [66 * n]: sorted: histL[33], histR[33]; else L[32], R[32] directly
-	float *sep;
+	uint32_t *kind;        // K_SPLIT: inner node; axis; K_SORTED: candidate planes ascend (always, except for NaN / inverted boxes); K_DONE: split chosen by the counting kernel
+	float *mn, *delta;     // candidate plane k = mn + k * delta
+	float *sep;            // chosen plane
 	uint32_t *cntL, *cntR;
-	uint32_t *childRefs, *leafCnt;
-	struct Trip *incl;     // inclusive scan of (split, childRefs, leafCnt), one pass for the three
-	__device__ uint32_t splitIdx( uint32_t i ) const;
-	__device__ uint32_t childStart( uint32_t i ) const;
-	__device__ uint32_t leafStart( uint32_t i ) const;
 };
 
-struct alignas( 16 ) Trip { uint32_t a, b, c, d; };
-struct TripSum
-{
-	__host__ __device__ Trip operator()( const Trip &x, const Trip &y ) const { return Trip{ x.a + y.a, x.b + y.b, x.c + y.c, 0u }; }
-};
-struct TripLoad
-{
-	const uint32_t *a, *b, *c;
-	__host__ __device__ Trip operator()( uint32_t i ) const { return Trip{ a[i], b[i], c[i], 0u }; }
-};
-// exclusive values = inclusive value - own contribution
-__device__ inline uint32_t NodeWork::splitIdx( uint32_t i ) const { return incl[i].a - split[i]; }
-__device__ inline uint32_t NodeWork::childStart( uint32_t i ) const { return incl[i].b - childRefs[i]; }
-__device__ inline uint32_t NodeWork::leafStart( uint32_t i ) const { return incl[i].c - leafCnt[i]; }
+constexpr int HIST = 2 * PARTS + 2;      // per node: left histogram [33], right histogram [33] (sorted planes); else L[32], R[32] at 0 and 33
+constexpr int HSLOTS = 32;               // nodes of one tile of references counted in LDS
+constexpr int G_REF = 1024, G_NODE = 256;  // blocks of a per-reference / per-node launch
+static_assert( PARTS == 32, "the split search gives one plane to each lane of half a wave" );
 
 __device__ inline float box_c( const float *b, int ax ) { return b[ax]; }
 __device__ inline float box_e( const float *b, int ax ) { return b[3 + ax]; }
 
-__global__ __launch_bounds__( TB ) void k_decide( LevelTab L, NodeWork W, uint32_t n, int depth, int maxDepth, int maxPrims )
+// contiguous share of n items for this block, a multiple of TB long
+__device__ inline void block_range( uint32_t n, uint32_t &b0, uint32_t &b1 )
 {
-	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i >= n )
-		return;
-	const float *b = L.box + 6ull * i;
-	const uint32_t cnt = L.count[i];
-	for ( int k = 0; k < 66; ++k )
-		W.hist[66ull * i + k] = 0u;
+	const uint32_t per = ( ( n + gridDim.x * TB - 1u ) / ( gridDim.x * TB ) ) * TB;
+	const uint64_t s = (uint64_t) blockIdx.x * per;
+	b0 = s < n ? (uint32_t) s : n;
+	b1 = s + per < n ? (uint32_t) ( s + per ) : n;
+}
+
+__device__ inline uint32_t wave_sum( uint32_t v )
+{
+	for ( int off = 32; off; off >>= 1 )
+		v += (uint32_t) __shfl_xor( (int) v, off );
+	return v;
+}
+
+// sum of N values over the block, returned to every thread (red: [TB / 64][N] words of LDS)
+template <int N>
+__device__ inline void block_sum( uint32_t ( &v )[N], uint32_t *red )
+{
+	for ( int k = 0; k < N; ++k )
+		v[k] = wave_sum( v[k] );
+	__syncthreads();
+	if ( ( threadIdx.x & 63 ) == 0 )
+		for ( int k = 0; k < N; ++k )
+			red[( threadIdx.x >> 6 ) * N + k] = v[k];
+	__syncthreads();
+	for ( int k = 0; k < N; ++k )
+	{
+		uint32_t s = 0;
+		for ( int w = 0; w < TB / 64; ++w )
+			s += red[w * N + k];
+		v[k] = s;
+	}
+}
+
+// leaf (count <= maxPrims or depth == maxDepth) or inner node with its split axis:
+// longest half extent, ties X > Y > Z (:945-957), and the candidate planes
+__device__ inline void decide_node( const NodeTab &T, uint32_t i, int depth, int maxDepth, int maxPrims )
+{
+	const float *b = T.box + 6ull * i;
+	const uint32_t cnt = T.count[i];
 	if ( cnt <= (uint32_t) maxPrims || depth == maxDepth )
 	{
-		W.split[i] = 0u;
-		W.leafCnt[i] = cnt;
-		W.childRefs[i] = 0u;
+		T.kind[i] = 0u;
 		return;
 	}
-	// longest half extent, ties X > Y > Z (:945-957)
 	float range = b[3];
 	int ax = 0;
 	if ( range < b[4] ) { range = b[4]; ax = 1; }
@@ -295,206 +328,477 @@ __global__ __launch_bounds__( TB ) void k_decide( LevelTab L, NodeWork W, uint32
 		if ( k && !( prev <= s ) ) sorted = false;
 		prev = s;
 	}
-	W.split[i] = 1u;
-	W.leafCnt[i] = 0u;
-	W.axis[i] = (uint32_t) ax;
-	W.sorted[i] = sorted ? 1u : 0u;
-	W.mn[i] = mn;
-	W.delta[i] = delta;
+	T.kind[i] = K_SPLIT | ( (uint32_t) ax << 1 ) | ( sorted ? K_SORTED : 0u );
+	T.mn[i] = mn;
+	T.delta[i] = delta;
 }
 
-// Counting goes through a histogram in LDS for the node the block's first
-// reference belongs to (near the root a node spans thousands of blocks, and
-// atomics of all of them on the same 66 words of HBM would be executed one
-// after the other); references of other nodes inside the block count directly.
-__global__ __launch_bounds__( TB ) void k_hist( NodeWork W, const uint32_t *refs, const uint32_t *refNode, uint32_t nRefs,
-	const float *ext, uint32_t nT )
+// the root and the state of level 0 (the state has been zeroed: a level that was never reached holds nothing)
+__global__ __launch_bounds__( 64 ) void k_root( BuildState *st, NodeTab T, const GeomInfo *geom, uint32_t nT, int maxDepth, int maxPrims )
 {
-	__shared__ uint32_t sh[66];
-	const uint32_t j = blockIdx.x * TB + threadIdx.x;
-	const uint32_t node0 = refNode[blockIdx.x * TB];
-	if ( threadIdx.x < 66 )
-		sh[threadIdx.x] = 0u;
-	__syncthreads();
-	if ( j < nRefs )
-	{
-		const uint32_t i = refNode[j];
-		if ( W.split[i] )
-		{
-			const uint32_t ax = W.axis[i], tri = refs[j];
-			const float a = ext[(size_t) ax * nT + tri], b = ext[( 3ull + ax ) * nT + tri];
-			const float mn = W.mn[i], delta = W.delta[i];
-			uint32_t *h = i == node0 ? sh : W.hist + 66ull * i;
-			if ( W.sorted[i] )
-			{
-				// lo = number of planes at or below the triangle's minimum, hi = number of planes below its maximum
-				int lo = 0, hi = 0;
-				for ( int step = PARTS / 2; step; step >>= 1 )
-				{
-					if ( !( a < mn + ( lo + step - 1 ) * delta ) ) lo += step;
-					if ( b > mn + ( hi + step - 1 ) * delta ) hi += step;
-				}
-				if ( lo < PARTS && !( a < mn + lo * delta ) ) ++lo;
-				if ( hi < PARTS && b > mn + hi * delta ) ++hi;
-				atomicAdd( &h[lo], 1u );
-				atomicAdd( &h[33 + hi], 1u );
-			}
-			else
-			{
-				for ( int k = 0; k < PARTS; ++k )
-				{
-					const float s = mn + k * delta;
-					if ( a < s ) atomicAdd( &h[k], 1u );
-					if ( b > s ) atomicAdd( &h[33 + k], 1u );
-				}
-			}
-		}
-	}
-	__syncthreads();
-	if ( threadIdx.x < 66 && sh[threadIdx.x] )
-		atomicAdd( &W.hist[66ull * node0 + threadIdx.x], sh[threadIdx.x] );
-}
-
-// SAH sweep of :591-857 on the counts: lowest index with the strictly smallest cost
-__global__ __launch_bounds__( TB ) void k_split( LevelTab L, NodeWork W, uint32_t n )
-{
-	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i >= n || !W.split[i] )
+	if ( threadIdx.x != 0 )
 		return;
-	const float *b = L.box + 6ull * i;
-	const int ax = (int) W.axis[i];
+	for ( int k = 0; k < 6; ++k )
+		T.box[k] = geom->box[k];
+	T.start[0] = 0u;
+	T.count[0] = nT;
+	decide_node( T, 0u, 0, maxDepth, maxPrims );
+	st->lv[0].nodes = 1u;
+	st->lv[0].refs = nT;
+}
+
+// SAH sweep of :591-857 on the counts of one node, by 32 lanes (lane l = plane l):
+// the lowest index with the strictly smallest cost.  h: the node's histogram (LDS or HBM).
+__device__ inline void sah_node( const NodeTab &T, uint32_t i, uint32_t kd, const uint32_t *h, uint32_t l )
+{
+	const float *b = T.box + 6ull * i;
+	const int ax = (int) ( ( kd >> 1 ) & 3u );
+	const bool sorted = ( kd & K_SORTED ) != 0u;
 	const float c = box_c( b, ax ), e = box_e( b, ax );
-	const float mn = W.mn[i], delta = W.delta[i];
+	const float mn = T.mn[i], delta = T.delta[i];
 	float eA, eB;
 	if ( ax == 0 ) { eA = b[4]; eB = b[5]; }
 	else if ( ax == 1 ) { eA = b[3]; eB = b[5]; }
 	else { eA = b[3]; eB = b[4]; }
 	const float area = eA * eB;
-	const uint32_t *h = W.hist + 66ull * i;
-	const bool sorted = W.sorted[i] != 0u;
-
-	// R[k] needs a suffix sum: total first
-	unsigned long long accR = 0;
+	// sorted planes: L[k] = histL[0 .. k], R[k] = histR[k + 1 .. 32]; else the counts themselves
+	uint32_t Lk = h[l], Rk = sorted ? h[33u + l + 1u] : h[33u + l];
 	if ( sorted )
-		for ( int k = 1; k <= PARTS; ++k ) accR += h[33 + k];
-	unsigned long long accL = 0;
-	float best = 0.0f, outSep = 0.0f;
-	unsigned long long cl = 0, cr = 0;
-	for ( int k = 0; k < PARTS; ++k )
-	{
-		unsigned long long Lk, Rk;
-		if ( sorted )
+		for ( uint32_t off = 1u; off < 32u; off <<= 1 )
 		{
-			accL += h[k];
-			Lk = accL;
-			Rk = accR;               // sum of histR[k+1 .. 32]
-			accR -= h[33 + k + 1];
+			const uint32_t up = (uint32_t) __shfl_up( (int) Lk, off, 32 ), dn = (uint32_t) __shfl_down( (int) Rk, off, 32 );
+			if ( l >= off ) Lk += up;
+			if ( l + off < 32u ) Rk += dn;
+		}
+	const float sep = mn + (int) l * delta;
+	const float sah = ( area + ( sep - c + e ) * ( eA + eB ) ) * (float) Lk + ( area + ( c + e - sep ) * ( eA + eB ) ) * (float) Rk;
+	// the reference keeps plane 0 unless a later cost is smaller (a NaN never is): plane 0 if its cost is a NaN,
+	// else the lowest index among the smallest costs that are numbers
+	const bool nan0 = __shfl( (int) ( sah != sah ), 0, 32 ) != 0;
+	float v = sah != sah ? __builtin_huge_valf() : sah;
+	uint32_t best = l;
+	for ( int off = 16; off; off >>= 1 )
+	{
+		const float ov = __shfl_xor( v, off, 32 );
+		const uint32_t ob = (uint32_t) __shfl_xor( (int) best, off, 32 );
+		if ( ov < v || ( ov == v && ob < best ) ) { v = ov; best = ob; }
+	}
+	if ( nan0 ) best = 0u;
+	if ( l == best )
+	{
+		T.sep[i] = sep;
+		T.cntL[i] = Lk;
+		T.cntR[i] = Rk;
+	}
+}
+
+__device__ inline void hist_clear( uint32_t *h, uint32_t l )
+{
+	h[l] = 0u;
+	h[l + 32u] = 0u;
+	if ( l < 2u ) h[64u + l] = 0u;
+}
+
+// Histogram of every triangle extent against the 32 planes of its node.  References are ordered by node, a block
+// takes a contiguous run of them in tiles of TB; the nodes a tile touches are counted in LDS (the first HSLOTS of
+// them; counts of the others go to HBM directly).  A node whose references all lie in the tile gets its split
+// chosen right here and never touches the histograms in HBM; the others' counts are added to theirs (a node that
+// spans tiles keeps its LDS counts from tile to tile: near the root thousands of tiles belong to one node, and
+// atomics of all of them on the same 66 words would be executed one after the other).
+__global__ __launch_bounds__( TB ) void k_hist( const BuildState *st, int depth, NodeTab T, uint32_t *hist, const uint32_t *refs,
+	const uint32_t *refNode, const float *ext, uint32_t nT )
+{
+	if ( st->overflow != OVF_NONE )
+		return;
+	uint32_t b0, b1;
+	block_range( st->lv[depth].refs, b0, b1 );
+	if ( b0 >= b1 )
+		return;
+	__shared__ uint32_t sh[HSLOTS * HIST];
+	for ( int k = threadIdx.x; k < HSLOTS * HIST; k += TB )
+		sh[k] = 0u;
+	__syncthreads();
+	for ( uint32_t j0 = b0; j0 < b1; j0 += TB )
+	{
+		const uint32_t tileEnd = j0 + TB < b1 ? j0 + TB : b1;
+		const uint32_t node0 = refNode[j0], nodeLast = refNode[tileEnd - 1u];
+		const uint32_t j = j0 + threadIdx.x;
+		if ( j < tileEnd )
+		{
+			const uint32_t i = refNode[j], kd = T.kind[i];
+			if ( kd & K_SPLIT )
+			{
+				const uint32_t ax = ( kd >> 1 ) & 3u, tri = refs[j];
+				const float a = ext[(size_t) ax * nT + tri], b = ext[( 3ull + ax ) * nT + tri];
+				const float mn = T.mn[i], delta = T.delta[i];
+				const uint32_t slot = i - node0;
+				const bool inLds = slot < (uint32_t) HSLOTS;
+				uint32_t *hl = sh + ( inLds ? slot : 0u ) * HIST, *hg = hist + (size_t) HIST * i;
+				if ( kd & K_SORTED )
+				{
+					// lo = number of planes at or below the triangle's minimum, hi = number of planes below its maximum
+					int lo = 0, hi = 0;
+					for ( int step = PARTS / 2; step; step >>= 1 )
+					{
+						if ( !( a < mn + ( lo + step - 1 ) * delta ) ) lo += step;
+						if ( b > mn + ( hi + step - 1 ) * delta ) hi += step;
+					}
+					if ( lo < PARTS && !( a < mn + lo * delta ) ) ++lo;
+					if ( hi < PARTS && b > mn + hi * delta ) ++hi;
+					if ( inLds ) { atomicAdd( &hl[lo], 1u ); atomicAdd( &hl[33 + hi], 1u ); }
+					else { atomicAdd( &hg[lo], 1u ); atomicAdd( &hg[33 + hi], 1u ); }
+				}
+				else
+				{
+					for ( int k = 0; k < PARTS; ++k )
+					{
+						const float s = mn + k * delta;
+						if ( a < s ) { if ( inLds ) atomicAdd( &hl[k], 1u ); else atomicAdd( &hg[k], 1u ); }
+						if ( b > s ) { if ( inLds ) atomicAdd( &hl[33 + k], 1u ); else atomicAdd( &hg[33 + k], 1u ); }
+					}
+				}
+			}
+		}
+		__syncthreads();
+		// half a wave per node counted in LDS
+		const bool keep0 = tileEnd < b1 && refNode[tileEnd] == node0;
+		const uint32_t span = nodeLast - node0 + 1u, nSlots = span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS;
+		const uint32_t l = threadIdx.x & 31u;
+		for ( uint32_t s = threadIdx.x >> 5; s < nSlots; s += TB / 32 )
+		{
+			const uint32_t i = node0 + s, kd = T.kind[i];
+			if ( !( kd & K_SPLIT ) )
+				continue;
+			uint32_t *h = sh + s * HIST;
+			const uint32_t first = T.start[i], cnt = T.count[i];
+			if ( first >= j0 && first + cnt <= tileEnd )
+			{
+				sah_node( T, i, kd, h, l );
+				hist_clear( h, l );
+				if ( l == 0u )
+					T.kind[i] = kd | K_DONE;
+			}
+			else if ( !( s == 0u && keep0 ) )
+			{
+				uint32_t *g = hist + (size_t) HIST * i;
+				for ( uint32_t k = l; k < (uint32_t) HIST; k += 32u )
+				{
+					const uint32_t v = h[k];
+					if ( v )
+					{
+						atomicAdd( &g[k], v );
+						h[k] = 0u;
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// the nodes whose split the counting kernel could not choose (they span tiles): from the histograms in HBM, which
+// are left zeroed for the next level; then this block's share of the level's sums
+__global__ __launch_bounds__( TB ) void k_split( const BuildState *st, int depth, NodeTab T, uint32_t *hist, uint4 *blockSums )
+{
+	if ( st->overflow != OVF_NONE )
+		return;
+	const uint32_t n = st->lv[depth].nodes;
+	if ( n == 0u )
+		return;
+	__shared__ uint32_t red[( TB / 64 ) * 4];
+	uint32_t b0, b1;
+	block_range( n, b0, b1 );
+	const uint32_t l = threadIdx.x & 31u;
+	for ( uint32_t i = b0 + ( threadIdx.x >> 5 ); i < b1; i += TB / 32 )
+	{
+		const uint32_t kd = T.kind[i];
+		if ( ( kd & ( K_SPLIT | K_DONE ) ) != K_SPLIT )
+			continue;
+		uint32_t *h = hist + (size_t) HIST * i;
+		sah_node( T, i, kd, h, l );
+		hist_clear( h, l );
+	}
+	__syncthreads();
+	uint32_t acc[4] = { 0u, 0u, 0u, 0u };
+	for ( uint32_t i = b0 + threadIdx.x; i < b1; i += TB )
+	{
+		if ( T.kind[i] & K_SPLIT )
+		{
+			const uint32_t cl = T.cntL[i], cr = T.cntR[i];
+			acc[0] += 1u;
+			acc[1] += cl + cr;
+			acc[3] += cl;
+		}
+		else
+			acc[2] += T.count[i];
+	}
+	block_sum( acc, red );
+	if ( threadIdx.x == 0 )
+		blockSums[blockIdx.x] = make_uint4( acc[0], acc[1], acc[2], acc[3] );
+}
+
+// Numbers the children (a scan over the level's nodes, in two steps: the sums of k_split's blocks, then inside the
+// block), writes the child boxes - slab split at sep (:1034-1073) -, decides leaf / inner node for them, writes
+// this level's records of the tree in level order, and the next level's state.  Every block works out the level's
+// totals for itself, so all of them agree whether the next level fits the work buffers.
+__global__ __launch_bounds__( TB ) void k_children( BuildState *st, int depth, NodeTab T, NodeTab N, const uint4 *blockSums, uint2 *info,
+	Caps caps, int maxDepth, int maxPrims )
+{
+	if ( st->overflow != OVF_NONE )
+		return;
+	const LevelState L = st->lv[depth];
+	const uint32_t n = L.nodes;
+	if ( n == 0u )
+		return;
+	__shared__ uint32_t red[( TB / 64 ) * 8];
+	__shared__ uint32_t waveTot[( TB / 64 ) * 4];
+	uint32_t pt[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };      // sums of the blocks before this one, of all blocks
+	for ( uint32_t b = threadIdx.x; b < gridDim.x; b += TB )
+	{
+		const uint4 v = blockSums[b];
+		if ( b < blockIdx.x ) { pt[0] += v.x; pt[1] += v.y; pt[2] += v.z; pt[3] += v.w; }
+		pt[4] += v.x; pt[5] += v.y; pt[6] += v.z; pt[7] += v.w;
+	}
+	block_sum( pt, red );
+	const uint32_t splits = pt[4], childRefs = pt[5], levelLeafRefs = pt[6];
+	const uint64_t nodesAfter = (uint64_t) L.nodeBase + n + 2ull * splits, leafAfter = (uint64_t) L.leafBase + levelLeafRefs;
+	uint32_t ovf = OVF_NONE, need = 0u;
+	if ( nodesAfter >= ( 1ull << 30 ) || leafAfter + childRefs >= ( 1ull << 30 ) ) ovf = OVF_LINKS;      // 30-bit links of the 8-byte node
+	else if ( 2ull * splits > caps.levelNodes ) { ovf = OVF_LEVEL_NODES; need = 2u * splits; }
+	else if ( childRefs > caps.refs ) { ovf = OVF_REFS; need = childRefs; }
+	else if ( nodesAfter > caps.nodesTotal ) { ovf = OVF_NODES; need = (uint32_t) nodesAfter; }
+	else if ( leafAfter > caps.leaf ) { ovf = OVF_LEAF; need = (uint32_t) leafAfter; }
+	if ( blockIdx.x == 0 && threadIdx.x == 0 )
+	{
+		if ( ovf != OVF_NONE )
+		{
+			st->overflow = ovf;
+			st->need = need;
 		}
 		else
 		{
-			Lk = h[k];
-			Rk = h[33 + k];
-		}
-		const float sep = mn + k * delta;
-		const float sah = ( area + ( sep - c + e ) * ( eA + eB ) ) * Lk + ( area + ( c + e - sep ) * ( eA + eB ) ) * Rk;
-		if ( k == 0 || sah < best )
-		{
-			best = sah;
-			outSep = sep;
-			cl = Lk;
-			cr = Rk;
+			LevelState nx;
+			nx.nodes = 2u * splits;
+			nx.refs = childRefs;
+			nx.nodeBase = L.nodeBase + n;
+			nx.leafBase = (uint32_t) leafAfter;
+			st->lv[depth + 1] = nx;
+			if ( splits == 0u )
+			{
+				st->nLevels = (uint32_t) depth + 1u;
+				st->nodesTotal = L.nodeBase + n;
+				st->leafRefs = (uint32_t) leafAfter;
+			}
 		}
 	}
-	W.sep[i] = outSep;
-	W.cntL[i] = (uint32_t) cl;
-	W.cntR[i] = (uint32_t) cr;
-	W.childRefs[i] = (uint32_t) ( cl + cr );
+	if ( ovf != OVF_NONE )
+		return;
+	uint32_t b0, b1;
+	block_range( n, b0, b1 );
+	uint32_t run[4] = { pt[0], pt[1], pt[2], pt[3] };
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	const uint32_t nextBase = L.nodeBase + n;
+	for ( uint32_t i0 = b0; i0 < b1; i0 += TB )
+	{
+		const uint32_t i = i0 + threadIdx.x;
+		const bool valid = i < b1;
+		uint32_t kd = 0u, own[4] = { 0u, 0u, 0u, 0u }, cnt = 0u, cl = 0u, cr = 0u;
+		if ( valid )
+		{
+			kd = T.kind[i];
+			cnt = T.count[i];
+			if ( kd & K_SPLIT )
+			{
+				cl = T.cntL[i];
+				cr = T.cntR[i];
+				own[0] = 1u; own[1] = cl + cr; own[3] = cl;
+			}
+			else
+				own[2] = cnt;
+		}
+		// inclusive scan inside the wave, wave totals through LDS
+		uint32_t inc[4];
+		for ( int k = 0; k < 4; ++k )
+		{
+			uint32_t v = own[k];
+			for ( uint32_t off = 1u; off < 64u; off <<= 1 )
+			{
+				const uint32_t up = (uint32_t) __shfl_up( (int) v, off );
+				if ( lane >= off ) v += up;
+			}
+			inc[k] = v;
+		}
+		__syncthreads();          // (the previous tile's wave totals have been read)
+		if ( lane == 63u )
+			for ( int k = 0; k < 4; ++k )
+				waveTot[w * 4 + k] = inc[k];
+		__syncthreads();
+		uint32_t ex[4];
+		for ( int k = 0; k < 4; ++k )
+		{
+			uint32_t before = run[k], all = 0u;
+			for ( uint32_t q = 0; q < TB / 64; ++q )
+			{
+				const uint32_t t = waveTot[q * 4 + k];
+				if ( q < w ) before += t;
+				all += t;
+			}
+			ex[k] = before + inc[k] - own[k];
+			run[k] += all;
+		}
+		if ( !valid )
+			continue;
+		T.excl[i] = make_uint4( ex[0], ex[1], ex[2], ex[3] );
+		if ( !( kd & K_SPLIT ) )
+		{
+			info[L.nodeBase + i] = make_uint2( L.leafBase + ex[2], ( cnt << 2 ) | 3u );
+			continue;
+		}
+		const float *b = T.box + 6ull * i;
+		const int ax = (int) ( ( kd >> 1 ) & 3u );
+		const float sep = T.sep[i];
+		const uint32_t c = 2u * ex[0];
+		float *bl = N.box + 6ull * c, *br = bl + 6;
+		for ( int k = 0; k < 6; ++k )
+			bl[k] = br[k] = b[k];
+		bl[ax] = 0.5f * ( box_c( b, ax ) - box_e( b, ax ) + sep );
+		bl[3 + ax] = 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) );
+		br[ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep );
+		br[3 + ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep );
+		N.start[c] = ex[1];
+		N.count[c] = cl;
+		N.start[c + 1] = ex[1] + cl;
+		N.count[c + 1] = cr;
+		decide_node( N, c, depth + 1, maxDepth, maxPrims );
+		decide_node( N, c + 1u, depth + 1, maxDepth, maxPrims );
+		info[L.nodeBase + i] = make_uint2( __float_as_uint( sep ), ( ( nextBase + c ) << 2 ) | (uint32_t) ax );
+	}
 }
 
-// child boxes: slab split at sep (:1034-1073); record of the node in level order
-__global__ __launch_bounds__( TB ) void k_children( LevelTab L, NodeWork W, LevelTab N, uint32_t n, uint2 *info, uint32_t idBase,
-	uint32_t nextBase, uint32_t leafPoolBase )
+// does reference j go to the left / right child of its node (min < sep / max > sep, :971-1029)
+struct RefSide
 {
-	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i >= n )
-		return;
-	if ( !W.split[i] )
-	{
-		info[idBase + i] = make_uint2( leafPoolBase + W.leafStart( i ), ( L.count[i] << 2 ) | 3u );
-		return;
-	}
-	const float *b = L.box + 6ull * i;
-	const int ax = (int) W.axis[i];
-	const float sep = W.sep[i];
-	const uint32_t c = 2u * W.splitIdx( i );
-	float *bl = N.box + 6ull * c, *br = bl + 6;
-	for ( int k = 0; k < 6; ++k )
-		bl[k] = br[k] = b[k];
-	bl[ax] = 0.5f * ( box_c( b, ax ) - box_e( b, ax ) + sep );
-	bl[3 + ax] = 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) );
-	br[ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep );
-	br[3 + ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep );
-	N.start[c] = W.childStart( i );
-	N.count[c] = W.cntL[i];
-	N.start[c + 1] = W.childStart( i ) + W.cntL[i];
-	N.count[c + 1] = W.cntR[i];
-	info[idBase + i] = make_uint2( __float_as_uint( sep ), ( ( nextBase + c ) << 2 ) | (uint32_t) ax );
-}
-
-// per reference: goes left (low word) / right (high word); evaluated on the
-// fly by the scan and again by the scatter, never stored
-struct RefFlags
-{
-	NodeWork W;
-	const uint32_t *refs, *refNode;
-	const float *ext;
-	uint32_t nT;
-	__host__ __device__ unsigned long long operator()( uint32_t j ) const
-	{
-		const uint32_t i = refNode[j];
-		unsigned long long f = 0ull;
-		if ( W.split[i] )
-		{
-			const uint32_t ax = W.axis[i], tri = refs[j];
-			const float sep = W.sep[i];
-			if ( ext[(size_t) ax * nT + tri] < sep ) f |= 1ull;
-			if ( ext[( 3ull + ax ) * nT + tri] > sep ) f |= 1ull << 32;
-		}
-		return f;
-	}
+	uint32_t node, kind, tri;
+	bool left, right;
 };
 
-// stable partition (:971-1029): the k-th reference of a node that goes left
-// becomes the k-th reference of its left child; leaves move to the leaf pool
-__global__ __launch_bounds__( TB ) void k_scatter( LevelTab L, RefFlags F, uint32_t nRefs,
-	const unsigned long long *scan, uint32_t *nextRefs, uint32_t *nextRefNode,
-	uint32_t *leafPool, uint32_t leafPoolBase, uint32_t *lostInPlane )
+__device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, const uint32_t *refNode, const float *ext, uint32_t nT, uint32_t j )
 {
-	const uint32_t j = blockIdx.x * TB + threadIdx.x;
-	if ( j >= nRefs )
-		return;
-	const NodeWork &W = F.W;
-	const uint32_t i = F.refNode[j], tri = F.refs[j], s0 = L.start[i];
-	if ( !W.split[i] )
+	RefSide r;
+	r.node = refNode[j];
+	r.kind = T.kind[r.node];
+	r.tri = refs[j];
+	r.left = r.right = false;
+	if ( r.kind & K_SPLIT )
 	{
-		leafPool[leafPoolBase + W.leafStart( i ) + ( j - s0 )] = tri;
-		return;
+		const uint32_t ax = ( r.kind >> 1 ) & 3u;
+		const float sep = T.sep[r.node];
+		r.left = ext[(size_t) ax * nT + r.tri] < sep;
+		r.right = ext[( 3ull + ax ) * nT + r.tri] > sep;
 	}
-	const unsigned long long f = F( j ), here = scan[j], base = scan[s0];
-	const uint32_t c = 2u * W.splitIdx( i );
-	if ( f == 0ull )
-		atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
-	if ( f & 1ull )
+	return r;
+}
+
+// references going left / right in every block's share of the level (the first step of the partition's scan)
+__global__ __launch_bounds__( TB ) void k_count( const BuildState *st, int depth, NodeTab T, const uint32_t *refs, const uint32_t *refNode,
+	const float *ext, uint32_t nT, uint2 *blockSums )
+{
+	if ( st->overflow != OVF_NONE )
+		return;
+	const uint32_t n = st->lv[depth].refs;
+	if ( n == 0u )
+		return;
+	__shared__ uint32_t red[( TB / 64 ) * 2];
+	uint32_t b0, b1;
+	block_range( n, b0, b1 );
+	uint32_t acc[2] = { 0u, 0u };
+	for ( uint32_t j = b0 + threadIdx.x; j < b1; j += TB )
 	{
-		const uint32_t p = W.childStart( i ) + ( (uint32_t) here - (uint32_t) base );
-		nextRefs[p] = tri;
-		nextRefNode[p] = c;
+		const RefSide r = ref_side( T, refs, refNode, ext, nT, j );
+		acc[0] += r.left ? 1u : 0u;
+		acc[1] += r.right ? 1u : 0u;
 	}
-	if ( f >> 32 )
+	block_sum( acc, red );
+	if ( threadIdx.x == 0 )
+		blockSums[blockIdx.x] = make_uint2( acc[0], acc[1] );
+}
+
+// Stable partition (:971-1029): the k-th reference of a node that goes left becomes the k-th reference of its left
+// child; references of leaves move to the leaf pool.  A reference's rank among those of its node that go left is its
+// rank among all of the level that go left, less the left counts of the nodes before its own (NodeTab::excl).
+__global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int depth, NodeTab T, const uint32_t *refs, const uint32_t *refNode,
+	const float *ext, uint32_t nT, const uint2 *blockSums, uint32_t *nextRefs, uint32_t *nextRefNode, uint32_t *leafPool,
+	uint32_t *lostInPlane )
+{
+	if ( st->overflow != OVF_NONE )
+		return;
+	const LevelState L = st->lv[depth];
+	uint32_t b0, b1;
+	block_range( L.refs, b0, b1 );
+	if ( b0 >= b1 )
+		return;
+	__shared__ uint32_t red[( TB / 64 ) * 2];
+	__shared__ uint32_t waveTot[( TB / 64 ) * 2];
+	uint32_t run[2] = { 0u, 0u };
+	for ( uint32_t b = threadIdx.x; b < blockIdx.x; b += TB )
 	{
-		const uint32_t p = W.childStart( i ) + W.cntL[i] + ( (uint32_t) ( here >> 32 ) - (uint32_t) ( base >> 32 ) );
-		nextRefs[p] = tri;
-		nextRefNode[p] = c + 1u;
+		const uint2 v = blockSums[b];
+		run[0] += v.x;
+		run[1] += v.y;
+	}
+	block_sum( run, red );
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	const unsigned long long below = ( 1ull << lane ) - 1ull;
+	for ( uint32_t j0 = b0; j0 < b1; j0 += TB )
+	{
+		const uint32_t j = j0 + threadIdx.x;
+		const bool valid = j < b1;
+		RefSide r;
+		r.node = r.kind = r.tri = 0u;
+		r.left = r.right = false;
+		if ( valid )
+			r = ref_side( T, refs, refNode, ext, nT, j );
+		const unsigned long long mL = __ballot( r.left ), mR = __ballot( r.right );
+		__syncthreads();          // (the previous tile's wave totals have been read)
+		if ( lane == 0u )
+		{
+			waveTot[w * 2] = (uint32_t) __popcll( mL );
+			waveTot[w * 2 + 1] = (uint32_t) __popcll( mR );
+		}
+		__syncthreads();
+		uint32_t gl = run[0], gr = run[1];
+		for ( uint32_t q = 0; q < TB / 64; ++q )
+		{
+			const uint32_t tl = waveTot[q * 2], tr = waveTot[q * 2 + 1];
+			if ( q < w ) { gl += tl; gr += tr; }
+			run[0] += tl;
+			run[1] += tr;
+		}
+		gl += (uint32_t) __popcll( mL & below );
+		gr += (uint32_t) __popcll( mR & below );
+		if ( !valid )
+			continue;
+		const uint4 ex = T.excl[r.node];
+		if ( !( r.kind & K_SPLIT ) )
+		{
+			leafPool[L.leafBase + ex.z + ( j - T.start[r.node] )] = r.tri;
+			continue;
+		}
+		const uint32_t c = 2u * ex.x;
+		if ( !r.left && !r.right )
+			atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
+		if ( r.left )
+		{
+			const uint32_t p = ex.y + ( gl - ex.w );
+			nextRefs[p] = r.tri;
+			nextRefNode[p] = c;
+		}
+		if ( r.right )
+		{
+			const uint32_t p = ex.y + T.cntL[r.node] + ( gr - ( ex.y - ex.w ) );
+			nextRefs[p] = r.tri;
+			nextRefNode[p] = c + 1u;
+		}
 	}
 }
 
@@ -726,58 +1030,44 @@ inline unsigned grid_of( size_t n ) { return (unsigned) ( ( n + TB - 1 ) / TB );
 
 struct Scratch
 {
-	DVec verts, tris, ext, refsA, refsB, nodeA, nodeB, scan, cub, info, leafPool, work, sub, order, geom;
-	uint32_t *hTotals = nullptr;
+	DVec verts, tris, ext, refsA, refsB, tabA, tabB, hist, sums, info, leafPool, sub, order, geom, state;
+	Caps caps = { 0u, 0u, 0u, 0u };
+	bool histClean = false;      // every entry of `hist` is zero (each level leaves it so; a build that failed half-way may not)
+	void *pinned = nullptr;      // BuildState + GeomInfo as the host reads them
 	void release()
 	{
-		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &nodeA, &nodeB, &scan, &cub, &info, &leafPool, &work, &sub, &order, &geom } )
+		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &tabA, &tabB, &hist, &sums, &info, &leafPool, &sub, &order, &geom, &state } )
 			v->release();
-		if ( hTotals ) (void) hipHostFree( hTotals );
-		hTotals = nullptr;
+		if ( pinned ) (void) hipHostFree( pinned );
+		pinned = nullptr;
+		caps = Caps{ 0u, 0u, 0u, 0u };
+		histClean = false;
 	}
 };
 thread_local Scratch g_scratch;
 thread_local int g_scratchDev = -1;
 
-// carve the per-level node tables out of one allocation
-int level_tab( DVec &buf, size_t n, hipStream_t s, LevelTab &t )
+// carve a level's node table out of one allocation
+int node_tab( DVec &buf, size_t n, hipStream_t s, NodeTab &t )
 {
-	if ( n == 0 ) n = 1;
-	if ( int rc = buf.reserve( n * ( 6 * sizeof( float ) + 2 * sizeof( uint32_t ) ), s ) ) return rc;
-	t.box = buf.as<float>();
-	t.start = (uint32_t *) ( t.box + 6 * n );
-	t.count = t.start + n;
-	return 0;
-}
-
-int node_work( DVec &buf, size_t n, hipStream_t s, NodeWork &w )
-{
-	if ( n == 0 ) n = 1;
-	if ( int rc = buf.reserve( n * ( 4 + 66 + 11 ) * sizeof( uint32_t ), s ) ) return rc;
+	if ( int rc = buf.reserve( n * 18 * sizeof( uint32_t ), s ) ) return rc;
 	uint32_t *p = buf.as<uint32_t>();
-	w.incl = (Trip *) p; p += 4 * n;          // first: 16-byte aligned
-	w.hist = p; p += 66 * n;
-	w.split = p; p += n;
-	w.axis = p; p += n;
-	w.sorted = p; p += n;
-	w.mn = (float *) p; p += n;
-	w.delta = (float *) p; p += n;
-	w.sep = (float *) p; p += n;
-	w.cntL = p; p += n;
-	w.cntR = p; p += n;
-	w.childRefs = p; p += n;
-	w.leafCnt = p; p += n;
+	t.excl = (uint4 *) p; p += 4 * n;          // first: 16-byte aligned
+	t.box = (float *) p; p += 6 * n;
+	t.start = p; p += n;
+	t.count = p; p += n;
+	t.kind = p; p += n;
+	t.mn = (float *) p; p += n;
+	t.delta = (float *) p; p += n;
+	t.sep = (float *) p; p += n;
+	t.cntL = p; p += n;
+	t.cntR = p; p += n;
 	return 0;
 }
 
-template <class In, class T>
-int exclusive_sum( DVec &cub, In in, T *out, size_t n, hipStream_t s )
+inline uint32_t cap_of( uint64_t want )
 {
-	size_t bytes = 0;
-	GCHK( hipcub::DeviceScan::ExclusiveSum( nullptr, bytes, in, out, (int) n, s ) );
-	if ( int rc = cub.reserve( bytes ? bytes : 16, s ) ) return rc;
-	GCHK( hipcub::DeviceScan::ExclusiveSum( cub.p, bytes, in, out, (int) n, s ) );
-	return 0;
+	return (uint32_t) ( want < ( 1ull << 30 ) ? want : ( 1ull << 30 ) );
 }
 
 } // namespace
@@ -847,10 +1137,10 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		g_scratchDev = dev;
 	}
 	Scratch &S = g_scratch;
-	if ( !S.hTotals )
-		GCHK( hipHostMalloc( (void **) &S.hTotals, 4 * sizeof( uint32_t ) + sizeof( GeomInfo ), hipHostMallocDefault ) );
-	uint32_t *hTotals = S.hTotals;
-	GeomInfo *hGeom = (GeomInfo *) ( S.hTotals + 4 );
+	if ( !S.pinned )
+		GCHK( hipHostMalloc( &S.pinned, sizeof( BuildState ) + sizeof( GeomInfo ), hipHostMallocDefault ) );
+	BuildState *hState = (BuildState *) S.pinned;
+	GeomInfo *hGeom = (GeomInfo *) ( hState + 1 );
 
 	// inputs; the index check, the highest material slot and the scene box are
 	// taken from the device copy (a host pass over 1 M triangles and their
@@ -861,99 +1151,104 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 	if ( nT ) GCHK( hipMemcpyAsync( S.tris.p, tris, sizeof( rt_triangle ) * nT, hipMemcpyHostToDevice, s ) );
 	if ( int rc = S.ext.reserve( 6 * sizeof( float ) * ( nT ? nT : 1 ), s ) ) return rc;
 	if ( int rc = S.geom.reserve( sizeof( GeomInfo ) + 6 * sizeof( float ) * BOX_BLOCKS, s ) ) return rc;
+	if ( int rc = S.state.reserve( sizeof( BuildState ), s ) ) return rc;
+	if ( int rc = S.sums.reserve( sizeof( uint4 ) * G_NODE + sizeof( uint2 ) * G_REF, s ) ) return rc;
 	GeomInfo *dGeom = S.geom.as<GeomInfo>();
+	BuildState *dState = S.state.as<BuildState>();
+	uint4 *nodeSums = S.sums.as<uint4>();
+	uint2 *refSums = (uint2 *) ( nodeSums + G_NODE );
 	float *boxPart = (float *) ( dGeom + 1 );
 	GCHK( hipMemsetAsync( dGeom, 0, sizeof( GeomInfo ), s ) );
-	if ( nT ) hipLaunchKernelGGL( k_extents, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
+	if ( nT ) LAUNCH( k_extents, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
 		vertexCount, S.ext.as<float>(), dGeom );
-
-	// level 0: the root holds every triangle in index order
-	DVec *refsCur = &S.refsA, *refsNext = &S.refsB, *tabCur = &S.nodeA, *tabNext = &S.nodeB;
-	if ( int rc = refsCur->reserve( 2 * sizeof( uint32_t ) * ( nT ? nT : 1 ), s ) ) return rc;
-	size_t refCap = refsCur->cap / ( 2 * sizeof( uint32_t ) );
-	uint32_t *refs = refsCur->as<uint32_t>(), *refNode = refs + refCap;
-	if ( nT ) hipLaunchKernelGGL( k_iota, dim3( grid_of( nT ) ), dim3( TB ), 0, s, refs, refNode, nT );
-	LevelTab cur;
-	if ( int rc = level_tab( *tabCur, 1, s, cur ) ) return rc;
 	{
 		const uint64_t want = ( vertexCount + TB - 1 ) / TB;
 		const int nPart = (int) ( want < 1 ? 1 : want > (uint64_t) BOX_BLOCKS ? (uint64_t) BOX_BLOCKS : want );
-		hipLaunchKernelGGL( k_box_partial, dim3( nPart ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), vertexCount, boxPart );
-		hipLaunchKernelGGL( k_box_final, dim3( 1 ), dim3( 64 ), 0, s, S.verts.as<rt_vertex>(), vertexCount, boxPart, nPart, nT, dGeom,
-			cur.box, cur.start, cur.count );
-		GCHK( hipMemcpyAsync( hGeom, dGeom, sizeof( GeomInfo ), hipMemcpyDeviceToHost, s ) );
-		GCHK( hipStreamSynchronize( s ) );
-		if ( hGeom->badIndex )
-			return 3;
-		out->maxMaterial = hGeom->maxMat;
-		out->bbox.center.x = hGeom->box[0]; out->bbox.center.y = hGeom->box[1]; out->bbox.center.z = hGeom->box[2];
-		out->bbox.extents.x = hGeom->box[3]; out->bbox.extents.y = hGeom->box[4]; out->bbox.extents.z = hGeom->box[5];
+		LAUNCH( k_box_partial, dim3( nPart ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), vertexCount, boxPart );
+		LAUNCH( k_box_final, dim3( 1 ), dim3( 64 ), 0, s, S.verts.as<rt_vertex>(), vertexCount, boxPart, nPart, dGeom );
 	}
 
-	std::vector<uint32_t> levelFirst, levelCount;
-	uint64_t nodesTotal = 0, leafRefs = 0;
-	uint32_t levelNodes = 1, levelRefs = nT;
-	for ( int depth = 0; ; ++depth )
+	// The levels.  How many references and nodes a level holds is known on the device only, so the work buffers
+	// are sized from the triangle count (and from what earlier builds of this thread needed); a build that
+	// outgrows one says so in its state, the buffer is doubled and the levels run again.
 	{
-		levelFirst.push_back( (uint32_t) nodesTotal );
-		levelCount.push_back( levelNodes );
-		if ( nodesTotal + levelNodes >= ( 1ull << 30 ) )
-			return 4;
-		NodeWork W;
-		if ( int rc = node_work( S.work, levelNodes, s, W ) ) return rc;
-		if ( int rc = S.info.reserve( sizeof( uint2 ) * ( nodesTotal + levelNodes ), s, sizeof( uint2 ) * nodesTotal ) ) return rc;
-
-		hipLaunchKernelGGL( k_decide, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, levelNodes, depth, maxDepth, maxPrims );
-		if ( levelRefs )
-			hipLaunchKernelGGL( k_hist, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, W, refs, refNode, levelRefs, S.ext.as<float>(), nT );
-		hipLaunchKernelGGL( k_split, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, levelNodes );
+		Caps want;
+		want.refs = cap_of( 6ull * nT + 65536 );
+		want.levelNodes = cap_of( (uint64_t) nT + 4096 );
+		want.nodesTotal = cap_of( 4ull * nT + 4096 );
+		want.leaf = cap_of( 8ull * nT + 65536 );
+		if ( S.caps.refs < want.refs ) S.caps.refs = want.refs;
+		if ( S.caps.levelNodes < want.levelNodes ) S.caps.levelNodes = want.levelNodes;
+		if ( S.caps.nodesTotal < want.nodesTotal ) S.caps.nodesTotal = want.nodesTotal;
+		if ( S.caps.leaf < want.leaf ) S.caps.leaf = want.leaf;
+	}
+	for ( int attempt = 0; ; ++attempt )
+	{
+		const Caps caps = S.caps;
+		NodeTab tab[2];
+		if ( int rc = S.refsA.reserve( 2 * sizeof( uint32_t ) * (size_t) caps.refs, s ) ) return rc;
+		if ( int rc = S.refsB.reserve( 2 * sizeof( uint32_t ) * (size_t) caps.refs, s ) ) return rc;
+		if ( int rc = node_tab( S.tabA, caps.levelNodes, s, tab[0] ) ) return rc;
+		if ( int rc = node_tab( S.tabB, caps.levelNodes, s, tab[1] ) ) return rc;
+		if ( int rc = S.info.reserve( sizeof( uint2 ) * (size_t) caps.nodesTotal, s ) ) return rc;
+		if ( int rc = S.leafPool.reserve( sizeof( uint32_t ) * ( (size_t) caps.leaf + 1 ), s ) ) return rc;
 		{
-			hipcub::TransformInputIterator<Trip, TripLoad, hipcub::CountingInputIterator<uint32_t>> in(
-				hipcub::CountingInputIterator<uint32_t>( 0u ), TripLoad{ W.split, W.childRefs, W.leafCnt } );
-			size_t bytes = 0;
-			GCHK( hipcub::DeviceScan::InclusiveScan( nullptr, bytes, in, W.incl, TripSum(), (int) levelNodes, s ) );
-			if ( int rc = S.cub.reserve( bytes ? bytes : 16, s ) ) return rc;
-			GCHK( hipcub::DeviceScan::InclusiveScan( S.cub.p, bytes, in, W.incl, TripSum(), (int) levelNodes, s ) );
+			const void *before = S.hist.p;
+			if ( int rc = S.hist.reserve( sizeof( uint32_t ) * HIST * (size_t) caps.levelNodes, s ) ) return rc;
+			if ( S.hist.p != before || !S.histClean )
+				GCHK( hipMemsetAsync( S.hist.p, 0, S.hist.cap, s ) );
+			S.histClean = false;
 		}
-		// the last inclusive value holds the three totals
-		GCHK( hipMemcpyAsync( hTotals, W.incl + ( levelNodes - 1 ), 3 * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+		uint32_t *refBuf[2] = { S.refsA.as<uint32_t>(), S.refsB.as<uint32_t>() };
+		if ( nT ) LAUNCH( k_iota, dim3( grid_of( nT ) ), dim3( TB ), 0, s, refBuf[0], refBuf[0] + caps.refs, nT );
+		GCHK( hipMemsetAsync( &dGeom->lostInPlane, 0, sizeof( uint32_t ), s ) );
+		GCHK( hipMemsetAsync( dState, 0, sizeof( BuildState ), s ) );
+		LAUNCH( k_root, dim3( 1 ), dim3( 64 ), 0, s, dState, tab[0], dGeom, nT, maxDepth, maxPrims );
+		for ( int depth = 0; depth <= maxDepth; ++depth )
+		{
+			const NodeTab &cur = tab[depth & 1], &next = tab[( depth + 1 ) & 1];
+			const uint32_t *refs = refBuf[depth & 1], *refNode = refs + caps.refs;
+			uint32_t *nRefs = refBuf[( depth + 1 ) & 1], *nRefNode = nRefs + caps.refs;
+			if ( nT )
+				LAUNCH( k_hist, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), refs, refNode,
+					S.ext.as<float>(), nT );
+			LAUNCH( k_split, dim3( G_NODE ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), nodeSums );
+			LAUNCH( k_children, dim3( G_NODE ), dim3( TB ), 0, s, dState, depth, cur, next, nodeSums, S.info.as<uint2>(), caps,
+				maxDepth, maxPrims );
+			if ( nT )
+			{
+				LAUNCH( k_count, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, refs, refNode, S.ext.as<float>(), nT, refSums );
+				LAUNCH( k_scatter, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, refs, refNode, S.ext.as<float>(), nT, refSums,
+					nRefs, nRefNode, S.leafPool.as<uint32_t>(), &dGeom->lostInPlane );
+			}
+		}
+		GCHK( hipMemcpyAsync( hState, dState, sizeof( BuildState ), hipMemcpyDeviceToHost, s ) );
+		GCHK( hipMemcpyAsync( hGeom, dGeom, sizeof( GeomInfo ), hipMemcpyDeviceToHost, s ) );
+		GCHK( hipGetLastError() );
 		GCHK( hipStreamSynchronize( s ) );
-		const uint32_t splits = hTotals[0], childRefs = hTotals[1], levelLeafRefs = hTotals[2];
-		if ( (uint64_t) splits * 2 + nodesTotal + levelNodes >= ( 1ull << 30 ) || leafRefs + levelLeafRefs + childRefs >= ( 1ull << 30 ) )
-			return 4;          // 30-bit links of the 8-byte node
-
-		// next level's tables and reference arrays, leaf pool
-		LevelTab next;
-		if ( int rc = level_tab( *tabNext, 2 * (size_t) splits, s, next ) ) return rc;
-		if ( int rc = refsNext->reserve( 2 * sizeof( uint32_t ) * ( childRefs ? childRefs : 1 ), s ) ) return rc;
-		const size_t nextCap = refsNext->cap / ( 2 * sizeof( uint32_t ) );
-		uint32_t *nRefs = refsNext->as<uint32_t>(), *nRefNode = nRefs + nextCap;
-		if ( int rc = S.leafPool.reserve( sizeof( uint32_t ) * ( leafRefs + levelLeafRefs + 1 ), s, sizeof( uint32_t ) * leafRefs ) ) return rc;
-
-		hipLaunchKernelGGL( k_children, dim3( grid_of( levelNodes ) ), dim3( TB ), 0, s, cur, W, next, levelNodes, S.info.as<uint2>(),
-			(uint32_t) nodesTotal, (uint32_t) ( nodesTotal + levelNodes ), (uint32_t) leafRefs );
-		if ( levelRefs )
-		{
-			if ( int rc = S.scan.reserve( sizeof( unsigned long long ) * levelRefs, s ) ) return rc;
-			const RefFlags F{ W, refs, refNode, S.ext.as<float>(), nT };
-			hipcub::TransformInputIterator<unsigned long long, RefFlags, hipcub::CountingInputIterator<uint32_t>> in(
-				hipcub::CountingInputIterator<uint32_t>( 0u ), F );
-			if ( int rc = exclusive_sum( S.cub, in, S.scan.as<unsigned long long>(), levelRefs, s ) ) return rc;
-			hipLaunchKernelGGL( k_scatter, dim3( grid_of( levelRefs ) ), dim3( TB ), 0, s, cur, F, levelRefs,
-				S.scan.as<unsigned long long>(), nRefs, nRefNode, S.leafPool.as<uint32_t>(), (uint32_t) leafRefs, &dGeom->lostInPlane );
-		}
-
-		nodesTotal += levelNodes;
-		leafRefs += levelLeafRefs;
-		if ( splits == 0 )
+		S.histClean = true;
+		if ( hGeom->badIndex )
+			return 3;
+		if ( hState->overflow == OVF_NONE )
 			break;
-		std::swap( refsCur, refsNext );
-		std::swap( tabCur, tabNext );
-		cur = next;
-		refs = nRefs;
-		refNode = nRefNode;
-		levelNodes = 2 * splits;
-		levelRefs = childRefs;
+		uint32_t *grow = hState->overflow == OVF_REFS ? &S.caps.refs : hState->overflow == OVF_LEVEL_NODES ? &S.caps.levelNodes :
+			hState->overflow == OVF_NODES ? &S.caps.nodesTotal : hState->overflow == OVF_LEAF ? &S.caps.leaf : nullptr;
+		if ( !grow || *grow >= ( 1u << 30 ) || attempt >= 64 )
+			return 4;          // 30-bit links of the 8-byte node
+		// (a level that did not fit says how much it holds; the levels below it will hold about as much again)
+		const uint64_t twice = 2ull * *grow, asked = 2ull * hState->need;
+		*grow = cap_of( twice > asked ? twice : asked );
+	}
+	out->maxMaterial = hGeom->maxMat;
+	out->bbox.center.x = hGeom->box[0]; out->bbox.center.y = hGeom->box[1]; out->bbox.center.z = hGeom->box[2];
+	out->bbox.extents.x = hGeom->box[3]; out->bbox.extents.y = hGeom->box[4]; out->bbox.extents.z = hGeom->box[5];
+	const int nLevels = (int) hState->nLevels;
+	const uint64_t nodesTotal = hState->nodesTotal, leafRefs = hState->leafRefs;
+	if ( nLevels < 1 || nLevels > maxDepth + 1 || nodesTotal == 0 )
+	{
+		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "kd build left an inconsistent state (%d levels, %llu nodes)", nLevels,
+			(unsigned long long) nodesTotal );
+		return 10;
 	}
 
 	// sizes bottom-up, positions top-down
@@ -961,12 +1256,14 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 	if ( int rc = S.sub.reserve( 5 * sizeof( uint32_t ) * (size_t) nNodes, s ) ) return rc;
 	uint32_t *subNodes = S.sub.as<uint32_t>(), *subRefs = subNodes + nNodes, *subDepth = subRefs + nNodes, *pos = subDepth + nNodes, *refPos = pos + nNodes;
 	const uint2 *info = S.info.as<uint2>();
-	for ( int d = (int) levelFirst.size() - 1; d >= 0; --d )
-		hipLaunchKernelGGL( k_sizes, dim3( grid_of( levelCount[d] ) ), dim3( TB ), 0, s, info, levelFirst[d], levelCount[d], subNodes, subRefs, subDepth );
+	for ( int d = nLevels - 1; d >= 0; --d )
+		LAUNCH( k_sizes, dim3( grid_of( hState->lv[d].nodes ) ), dim3( TB ), 0, s, info, hState->lv[d].nodeBase, hState->lv[d].nodes,
+			subNodes, subRefs, subDepth );
 	GCHK( hipMemsetAsync( pos, 0, sizeof( uint32_t ), s ) );
 	GCHK( hipMemsetAsync( refPos, 0, sizeof( uint32_t ), s ) );
-	for ( size_t d = 0; d < levelFirst.size(); ++d )
-		hipLaunchKernelGGL( k_positions, dim3( grid_of( levelCount[d] ) ), dim3( TB ), 0, s, info, levelFirst[d], levelCount[d], subNodes, subRefs, pos, refPos );
+	for ( int d = 0; d < nLevels; ++d )
+		LAUNCH( k_positions, dim3( grid_of( hState->lv[d].nodes ) ), dim3( TB ), 0, s, info, hState->lv[d].nodeBase, hState->lv[d].nodes,
+			subNodes, subRefs, pos, refPos );
 	uint32_t rootDepth = 0;
 	GCHK( hipMemcpyAsync( &rootDepth, subDepth, sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
 
@@ -993,21 +1290,21 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		}
 	}
 	if ( int rc = S.order.reserve( sizeof( uint32_t ) * ( (size_t) nRecs + 1 ), s ) ) { rt_kdtree_device_release( out ); return rc; }
-	hipLaunchKernelGGL( k_emit, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, info, nNodes, pos, refPos, S.leafPool.as<uint32_t>(),
+	LAUNCH_OR( rt_kdtree_device_release( out ), k_emit, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, info, nNodes, pos, refPos, S.leafPool.as<uint32_t>(),
 		(rt_hip_kdnode *) out->nodes, S.order.as<uint32_t>() );
-	hipLaunchKernelGGL( k_records, dim3( grid_of( (size_t) nRecs + 1 ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(),
+	LAUNCH_OR( rt_kdtree_device_release( out ), k_records, dim3( grid_of( (size_t) nRecs + 1 ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(),
 		S.order.as<uint32_t>(), nRecs, (rt_hip_trirec *) out->recs );
 	if ( nT )
-		hipLaunchKernelGGL( k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
+		LAUNCH_OR( rt_kdtree_device_release( out ), k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
 			(rt_hip_trishade *) out->shade );
 	if ( twoLists )
 	{
 		rt_hip_trirec *recs = (rt_hip_trirec *) out->recs;
-		hipLaunchKernelGGL( k_leaf_full, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (const rt_hip_kdnode *) out->nodes, nNodes, nRecs,
+		LAUNCH_OR( rt_kdtree_device_release( out ), k_leaf_full, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (const rt_hip_kdnode *) out->nodes, nNodes, nRecs,
 			(rt_hip_leaf_full *) out->leafFull );
 		GCHK( hipMemcpyAsync( recs + nRecs, recs, sizeof( rt_hip_trirec ) * (size_t) nRecs, hipMemcpyDeviceToDevice, s ) );
 		GCHK( hipMemsetAsync( recs + 2 * (size_t) nRecs, 0, sizeof( rt_hip_trirec ), s ) );       // the spare record at the very end
-		hipLaunchKernelGGL( k_prune_leaves, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (rt_hip_kdnode *) out->nodes, nNodes,
+		LAUNCH_OR( rt_kdtree_device_release( out ), k_prune_leaves, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (rt_hip_kdnode *) out->nodes, nNodes,
 			recs, dGeom, opts->pruneLeaves );
 	}
 	hipError_t e = hipGetLastError();
