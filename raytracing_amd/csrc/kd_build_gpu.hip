@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 
 #include "rt_kdtree.h"
 
@@ -252,27 +253,43 @@ struct NodeTab
 	uint4 *excl;           // over the nodes before this one: x inner nodes, y references handed to children, z references in leaves, w references handed to left children
 	float *box;            // [6 * n]: centre xyz, half extent xyz
 	uint32_t *start, *count;
-	uint32_t *kind;        // K_SPLIT: inner node; axis; K_SORTED: candidate planes ascend (always, except for NaN / inverted boxes); K_DONE: split chosen by the counting kernel
+	uint32_t *parent;      // index in the level above
+	uint32_t *kind;        // K_SPLIT: inner node; axis; K_SORTED: candidate planes ascend (always, except for NaN / inverted boxes); K_DONE: split chosen by the kernel that counted
 	float *mn, *delta;     // candidate plane k = mn + k * delta
 	float *sep;            // chosen plane
 	uint32_t *cntL, *cntR;
 };
+constexpr int NODE_TAB_WORDS = 4 + 6 + 9;
 
 constexpr int HIST = 2 * PARTS + 2;      // per node: left histogram [33], right histogram [33] (sorted planes); else L[32], R[32] at 0 and 33
-constexpr int HSLOTS = 32;               // nodes of one tile of references counted in LDS
-constexpr int G_REF = 1024, G_NODE = 256;  // blocks of a per-reference / per-node launch
+constexpr int HSLOTS = 64;               // nodes of one tile of references counted in LDS
+constexpr int G_REF = 4096, G_NODE = 256;  // blocks of the per-reference / per-node part of a launch
+constexpr int SPLIT_FINER = 8;           // k_split's blocks take an eighth of a k_children block's nodes each
 static_assert( PARTS == 32, "the split search gives one plane to each lane of half a wave" );
 
 __device__ inline float box_c( const float *b, int ax ) { return b[ax]; }
 __device__ inline float box_e( const float *b, int ax ) { return b[3 + ax]; }
 
-// contiguous share of n items for this block, a multiple of TB long
-__device__ inline void block_range( uint32_t n, uint32_t &b0, uint32_t &b1 )
+// contiguous share of n nodes for block blk of nBlocks, a multiple of TB long
+__device__ inline uint32_t node_share( uint32_t n, uint32_t nBlocks ) { return ( ( n + nBlocks * TB - 1u ) / ( nBlocks * TB ) ) * TB; }
+
+__device__ inline void share_of( uint32_t n, uint32_t per, uint32_t blk, uint32_t &b0, uint32_t &b1 )
 {
-	const uint32_t per = ( ( n + gridDim.x * TB - 1u ) / ( gridDim.x * TB ) ) * TB;
-	const uint64_t s = (uint64_t) blockIdx.x * per;
+	const uint64_t s = (uint64_t) blk * per;
 	b0 = s < n ? (uint32_t) s : n;
 	b1 = s + per < n ? (uint32_t) ( s + per ) : n;
+}
+
+// Contiguous share of a level's references for block blk of nBlocks, in tiles of TB.  Near the root a node holds so
+// many references that its counts would be flushed by thousands of blocks, one atomic after the other on the same 66
+// words: there a block takes more tiles (it keeps the counts of a node in LDS from tile to tile), so that a node
+// is shared by about 512 blocks at most.
+__device__ inline void ref_share( const LevelState &L, uint32_t nBlocks, uint32_t blk, uint32_t &b0, uint32_t &b1 )
+{
+	uint32_t tiles = ( L.refs + nBlocks * TB - 1u ) / ( nBlocks * TB );
+	const uint32_t perNode = L.refs / ( L.nodes ? L.nodes : 1u ) / ( 512u * TB );
+	if ( tiles < perNode ) tiles = perNode;
+	share_of( L.refs, tiles * TB, blk, b0, b1 );
 }
 
 __device__ inline uint32_t wave_sum( uint32_t v )
@@ -304,10 +321,8 @@ __device__ inline void block_sum( uint32_t ( &v )[N], uint32_t *red )
 
 // leaf (count <= maxPrims or depth == maxDepth) or inner node with its split axis:
 // longest half extent, ties X > Y > Z (:945-957), and the candidate planes
-__device__ inline void decide_node( const NodeTab &T, uint32_t i, int depth, int maxDepth, int maxPrims )
+__device__ inline void decide_node( const NodeTab &T, uint32_t i, const float *b, uint32_t cnt, int depth, int maxDepth, int maxPrims )
 {
-	const float *b = T.box + 6ull * i;
-	const uint32_t cnt = T.count[i];
 	if ( cnt <= (uint32_t) maxPrims || depth == maxDepth )
 	{
 		T.kind[i] = 0u;
@@ -338,11 +353,13 @@ __global__ __launch_bounds__( 64 ) void k_root( BuildState *st, NodeTab T, const
 {
 	if ( threadIdx.x != 0 )
 		return;
+	float b[6];
 	for ( int k = 0; k < 6; ++k )
-		T.box[k] = geom->box[k];
+		T.box[k] = b[k] = geom->box[k];
 	T.start[0] = 0u;
 	T.count[0] = nT;
-	decide_node( T, 0u, 0, maxDepth, maxPrims );
+	T.parent[0] = 0u;
+	decide_node( T, 0u, b, nT, 0, maxDepth, maxPrims );
 	st->lv[0].nodes = 1u;
 	st->lv[0].refs = nT;
 }
@@ -399,19 +416,90 @@ __device__ inline void hist_clear( uint32_t *h, uint32_t l )
 	if ( l < 2u ) h[64u + l] = 0u;
 }
 
-// Histogram of every triangle extent against the 32 planes of its node.  References are ordered by node, a block
-// takes a contiguous run of them in tiles of TB; the nodes a tile touches are counted in LDS (the first HSLOTS of
-// them; counts of the others go to HBM directly).  A node whose references all lie in the tile gets its split
-// chosen right here and never touches the histograms in HBM; the others' counts are added to theirs (a node that
-// spans tiles keeps its LDS counts from tile to tile: near the root thousands of tiles belong to one node, and
-// atomics of all of them on the same 66 words would be executed one after the other).
+// One triangle extent [a, b] against the 32 planes of node i of table T: into the node's slot of the LDS histograms
+// when it has one (slot = node index - first node of the tile), else into its histogram in HBM.
+__device__ inline void hist_add( const NodeTab &T, uint32_t i, uint32_t kd, uint32_t tri, const float *ext, uint32_t nT, uint32_t first,
+	uint32_t *sh, uint32_t *hist )
+{
+	const uint32_t ax = ( kd >> 1 ) & 3u;
+	const float a = ext[(size_t) ax * nT + tri], b = ext[( 3ull + ax ) * nT + tri];
+	const float mn = T.mn[i], delta = T.delta[i];
+	const uint32_t slot = i - first;
+	const bool inLds = slot < (uint32_t) HSLOTS;
+	uint32_t *hl = sh + ( inLds ? slot : 0u ) * HIST, *hg = hist + (size_t) HIST * i;
+	if ( kd & K_SORTED )
+	{
+		// lo = number of planes at or below the triangle's minimum, hi = number of planes below its maximum
+		int lo = 0, hi = 0;
+		for ( int step = PARTS / 2; step; step >>= 1 )
+		{
+			if ( !( a < mn + ( lo + step - 1 ) * delta ) ) lo += step;
+			if ( b > mn + ( hi + step - 1 ) * delta ) hi += step;
+		}
+		if ( lo < PARTS && !( a < mn + lo * delta ) ) ++lo;
+		if ( hi < PARTS && b > mn + hi * delta ) ++hi;
+		if ( inLds ) { atomicAdd( &hl[lo], 1u ); atomicAdd( &hl[33 + hi], 1u ); }
+		else { atomicAdd( &hg[lo], 1u ); atomicAdd( &hg[33 + hi], 1u ); }
+	}
+	else
+	{
+		for ( int k = 0; k < PARTS; ++k )
+		{
+			const float s = mn + k * delta;
+			if ( a < s ) { if ( inLds ) atomicAdd( &hl[k], 1u ); else atomicAdd( &hg[k], 1u ); }
+			if ( b > s ) { if ( inLds ) atomicAdd( &hl[33 + k], 1u ); else atomicAdd( &hg[33 + k], 1u ); }
+		}
+	}
+}
+
+// After a tile of references has been counted: half a wave per node that has a slot in LDS (nodes first ..
+// first + nSlots - 1 of table T).  A node all of whose references were in this tile gets its split chosen right
+// here and never touches the histograms in HBM; the first `keep` slots stay as they are (their nodes go on in the
+// next tile); the counts of the others are added to theirs in HBM.
+template <class Complete>
+__device__ inline void finish_slots( const NodeTab &T, uint32_t first, uint32_t nSlots, uint32_t keep, uint32_t *sh, uint32_t *hist, Complete complete )
+{
+	const uint32_t l = threadIdx.x & 31u;
+	for ( uint32_t s = threadIdx.x >> 5; s < nSlots; s += TB / 32 )
+	{
+		const uint32_t i = first + s, kd = T.kind[i];
+		if ( !( kd & K_SPLIT ) )
+			continue;
+		uint32_t *h = sh + s * HIST;
+		if ( complete( i ) )
+		{
+			sah_node( T, i, kd, h, l );
+			hist_clear( h, l );
+			if ( l == 0u )
+				T.kind[i] = kd | K_DONE;
+		}
+		else if ( s >= keep )
+		{
+			uint32_t *g = hist + (size_t) HIST * i;
+			for ( uint32_t k = l; k < (uint32_t) HIST; k += 32u )
+			{
+				const uint32_t v = h[k];
+				if ( v )
+				{
+					atomicAdd( &g[k], v );
+					h[k] = 0u;
+				}
+			}
+		}
+	}
+}
+
+// Histogram of every triangle extent against the 32 planes of its node, for the root level (below it the
+// partition counts for the level it fills, k_scatter).  References are ordered by node, a block takes a contiguous
+// run of them in tiles of TB; the nodes a tile touches are counted in LDS (the first HSLOTS of them).
 __global__ __launch_bounds__( TB ) void k_hist( const BuildState *st, int depth, NodeTab T, uint32_t *hist, const uint32_t *refs,
 	const uint32_t *refNode, const float *ext, uint32_t nT )
 {
 	if ( st->overflow != OVF_NONE )
 		return;
+	const LevelState L = st->lv[depth];
 	uint32_t b0, b1;
-	block_range( st->lv[depth].refs, b0, b1 );
+	ref_share( L, gridDim.x, blockIdx.x, b0, b1 );
 	if ( b0 >= b1 )
 		return;
 	__shared__ uint32_t sh[HSLOTS * HIST];
@@ -427,77 +515,20 @@ __global__ __launch_bounds__( TB ) void k_hist( const BuildState *st, int depth,
 		{
 			const uint32_t i = refNode[j], kd = T.kind[i];
 			if ( kd & K_SPLIT )
-			{
-				const uint32_t ax = ( kd >> 1 ) & 3u, tri = refs[j];
-				const float a = ext[(size_t) ax * nT + tri], b = ext[( 3ull + ax ) * nT + tri];
-				const float mn = T.mn[i], delta = T.delta[i];
-				const uint32_t slot = i - node0;
-				const bool inLds = slot < (uint32_t) HSLOTS;
-				uint32_t *hl = sh + ( inLds ? slot : 0u ) * HIST, *hg = hist + (size_t) HIST * i;
-				if ( kd & K_SORTED )
-				{
-					// lo = number of planes at or below the triangle's minimum, hi = number of planes below its maximum
-					int lo = 0, hi = 0;
-					for ( int step = PARTS / 2; step; step >>= 1 )
-					{
-						if ( !( a < mn + ( lo + step - 1 ) * delta ) ) lo += step;
-						if ( b > mn + ( hi + step - 1 ) * delta ) hi += step;
-					}
-					if ( lo < PARTS && !( a < mn + lo * delta ) ) ++lo;
-					if ( hi < PARTS && b > mn + hi * delta ) ++hi;
-					if ( inLds ) { atomicAdd( &hl[lo], 1u ); atomicAdd( &hl[33 + hi], 1u ); }
-					else { atomicAdd( &hg[lo], 1u ); atomicAdd( &hg[33 + hi], 1u ); }
-				}
-				else
-				{
-					for ( int k = 0; k < PARTS; ++k )
-					{
-						const float s = mn + k * delta;
-						if ( a < s ) { if ( inLds ) atomicAdd( &hl[k], 1u ); else atomicAdd( &hg[k], 1u ); }
-						if ( b > s ) { if ( inLds ) atomicAdd( &hl[33 + k], 1u ); else atomicAdd( &hg[33 + k], 1u ); }
-					}
-				}
-			}
+				hist_add( T, i, kd, refs[j], ext, nT, node0, sh, hist );
 		}
 		__syncthreads();
-		// half a wave per node counted in LDS
-		const bool keep0 = tileEnd < b1 && refNode[tileEnd] == node0;
-		const uint32_t span = nodeLast - node0 + 1u, nSlots = span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS;
-		const uint32_t l = threadIdx.x & 31u;
-		for ( uint32_t s = threadIdx.x >> 5; s < nSlots; s += TB / 32 )
-		{
-			const uint32_t i = node0 + s, kd = T.kind[i];
-			if ( !( kd & K_SPLIT ) )
-				continue;
-			uint32_t *h = sh + s * HIST;
-			const uint32_t first = T.start[i], cnt = T.count[i];
-			if ( first >= j0 && first + cnt <= tileEnd )
-			{
-				sah_node( T, i, kd, h, l );
-				hist_clear( h, l );
-				if ( l == 0u )
-					T.kind[i] = kd | K_DONE;
-			}
-			else if ( !( s == 0u && keep0 ) )
-			{
-				uint32_t *g = hist + (size_t) HIST * i;
-				for ( uint32_t k = l; k < (uint32_t) HIST; k += 32u )
-				{
-					const uint32_t v = h[k];
-					if ( v )
-					{
-						atomicAdd( &g[k], v );
-						h[k] = 0u;
-					}
-				}
-			}
-		}
+		const uint32_t keep = tileEnd < b1 && refNode[tileEnd] == node0 ? 1u : 0u;
+		const uint32_t span = nodeLast - node0 + 1u;
+		finish_slots( T, node0, span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS, keep, sh, hist,
+			[&]( uint32_t i ) { const uint32_t first = T.start[i]; return first >= j0 && first + T.count[i] <= tileEnd; } );
 		__syncthreads();
 	}
 }
 
-// the nodes whose split the counting kernel could not choose (they span tiles): from the histograms in HBM, which
-// are left zeroed for the next level; then this block's share of the level's sums
+// The nodes whose split the counting kernel could not choose (they span tiles): from the histograms in HBM, which
+// are left zeroed for the next level; then the sums of this block's nodes for k_children's scan.  A block takes one
+// SPLIT_FINER-th of a k_children block's nodes (the splits are a chain of dependent loads per node).
 __global__ __launch_bounds__( TB ) void k_split( const BuildState *st, int depth, NodeTab T, uint32_t *hist, uint4 *blockSums )
 {
 	if ( st->overflow != OVF_NONE )
@@ -506,43 +537,85 @@ __global__ __launch_bounds__( TB ) void k_split( const BuildState *st, int depth
 	if ( n == 0u )
 		return;
 	__shared__ uint32_t red[( TB / 64 ) * 4];
+	__shared__ uint32_t todo[TB], nTodo;
 	uint32_t b0, b1;
-	block_range( n, b0, b1 );
+	share_of( n, node_share( n, G_NODE ) / SPLIT_FINER, blockIdx.x, b0, b1 );
 	const uint32_t l = threadIdx.x & 31u;
-	for ( uint32_t i = b0 + ( threadIdx.x >> 5 ); i < b1; i += TB / 32 )
-	{
-		const uint32_t kd = T.kind[i];
-		if ( ( kd & ( K_SPLIT | K_DONE ) ) != K_SPLIT )
-			continue;
-		uint32_t *h = hist + (size_t) HIST * i;
-		sah_node( T, i, kd, h, l );
-		hist_clear( h, l );
-	}
-	__syncthreads();
 	uint32_t acc[4] = { 0u, 0u, 0u, 0u };
-	for ( uint32_t i = b0 + threadIdx.x; i < b1; i += TB )
+	for ( uint32_t i0 = b0; i0 < b1; i0 += TB )          // (b0 == b1: nothing but the zero sums)
 	{
-		if ( T.kind[i] & K_SPLIT )
+		if ( threadIdx.x == 0 )
+			nTodo = 0u;
+		__syncthreads();
+		const uint32_t i = i0 + threadIdx.x;
+		uint32_t kd = 0u;
+		if ( i < b1 )
 		{
-			const uint32_t cl = T.cntL[i], cr = T.cntR[i];
-			acc[0] += 1u;
-			acc[1] += cl + cr;
-			acc[3] += cl;
+			kd = T.kind[i];
+			if ( ( kd & ( K_SPLIT | K_DONE ) ) == K_SPLIT )
+				todo[atomicAdd( &nTodo, 1u )] = i;
 		}
-		else
-			acc[2] += T.count[i];
+		__syncthreads();
+		const uint32_t m = nTodo;
+		for ( uint32_t q = threadIdx.x >> 5; q < m; q += TB / 32 )
+		{
+			const uint32_t ni = todo[q];
+			uint32_t *h = hist + (size_t) HIST * ni;
+			sah_node( T, ni, T.kind[ni], h, l );
+			hist_clear( h, l );
+		}
+		__syncthreads();
+		if ( i < b1 )
+		{
+			if ( kd & K_SPLIT )
+			{
+				const uint32_t cl = T.cntL[i], cr = T.cntR[i];
+				acc[0] += 1u;
+				acc[1] += cl + cr;
+				acc[3] += cl;
+			}
+			else
+				acc[2] += T.count[i];
+		}
 	}
 	block_sum( acc, red );
 	if ( threadIdx.x == 0 )
 		blockSums[blockIdx.x] = make_uint4( acc[0], acc[1], acc[2], acc[3] );
 }
 
-// Numbers the children (a scan over the level's nodes, in two steps: the sums of k_split's blocks, then inside the
-// block), writes the child boxes - slab split at sep (:1034-1073) -, decides leaf / inner node for them, writes
-// this level's records of the tree in level order, and the next level's state.  Every block works out the level's
-// totals for itself, so all of them agree whether the next level fits the work buffers.
-__global__ __launch_bounds__( TB ) void k_children( BuildState *st, int depth, NodeTab T, NodeTab N, const uint4 *blockSums, uint2 *info,
-	Caps caps, int maxDepth, int maxPrims )
+// does reference j go to the left / right child of its node (min < sep / max > sep, :971-1029)
+struct RefSide
+{
+	uint32_t node, kind, tri;
+	bool left, right;
+};
+
+__device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, const uint32_t *refNode, const float *ext, uint32_t nT, uint32_t j )
+{
+	RefSide r;
+	r.node = refNode[j];
+	r.kind = T.kind[r.node];
+	r.tri = refs[j];
+	r.left = r.right = false;
+	if ( r.kind & K_SPLIT )
+	{
+		const uint32_t ax = ( r.kind >> 1 ) & 3u;
+		const float sep = T.sep[r.node];
+		r.left = ext[(size_t) ax * nT + r.tri] < sep;
+		r.right = ext[( 3ull + ax ) * nT + r.tri] > sep;
+	}
+	return r;
+}
+
+// Two independent pieces of work in one launch (both need nothing but k_split's results).
+// Blocks [0, G_NODE): number the children (a scan over the level's nodes, in two steps: the sums of k_split's blocks,
+// then inside the block), write the child boxes - slab split at sep (:1034-1073) -, decide leaf / inner node for
+// them, write this level's records of the tree in level order, and the next level's state.  Every block works out the
+// level's totals for itself, so all of them agree whether the next level fits the work buffers.
+// Blocks [G_NODE, G_NODE + G_REF): references going left / right in every block's share of the level (the first
+// step of the partition's scan).
+__global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int depth, NodeTab T, NodeTab N, const uint4 *blockSums, uint2 *info,
+	Caps caps, int maxDepth, int maxPrims, const uint32_t *refs, const uint32_t *refNode, const float *ext, uint32_t nT, uint2 *refSums )
 {
 	if ( st->overflow != OVF_NONE )
 		return;
@@ -552,11 +625,27 @@ __global__ __launch_bounds__( TB ) void k_children( BuildState *st, int depth, N
 		return;
 	__shared__ uint32_t red[( TB / 64 ) * 8];
 	__shared__ uint32_t waveTot[( TB / 64 ) * 4];
-	uint32_t pt[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };      // sums of the blocks before this one, of all blocks
-	for ( uint32_t b = threadIdx.x; b < gridDim.x; b += TB )
+	if ( blockIdx.x >= (uint32_t) G_NODE )
+	{
+		uint32_t b0, b1;
+		ref_share( L, G_REF, blockIdx.x - G_NODE, b0, b1 );
+		uint32_t acc[2] = { 0u, 0u };
+		for ( uint32_t j = b0 + threadIdx.x; j < b1; j += TB )
+		{
+			const RefSide r = ref_side( T, refs, refNode, ext, nT, j );
+			acc[0] += r.left ? 1u : 0u;
+			acc[1] += r.right ? 1u : 0u;
+		}
+		block_sum( acc, red );
+		if ( threadIdx.x == 0 )
+			refSums[blockIdx.x - G_NODE] = make_uint2( acc[0], acc[1] );
+		return;
+	}
+	uint32_t pt[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };      // sums of the nodes before this block's, of all nodes
+	for ( uint32_t b = threadIdx.x; b < (uint32_t) ( G_NODE * SPLIT_FINER ); b += TB )
 	{
 		const uint4 v = blockSums[b];
-		if ( b < blockIdx.x ) { pt[0] += v.x; pt[1] += v.y; pt[2] += v.z; pt[3] += v.w; }
+		if ( b < blockIdx.x * SPLIT_FINER ) { pt[0] += v.x; pt[1] += v.y; pt[2] += v.z; pt[3] += v.w; }
 		pt[4] += v.x; pt[5] += v.y; pt[6] += v.z; pt[7] += v.w;
 	}
 	block_sum( pt, red );
@@ -594,7 +683,7 @@ __global__ __launch_bounds__( TB ) void k_children( BuildState *st, int depth, N
 	if ( ovf != OVF_NONE )
 		return;
 	uint32_t b0, b1;
-	block_range( n, b0, b1 );
+	share_of( n, node_share( n, G_NODE ), blockIdx.x, b0, b1 );
 	uint32_t run[4] = { pt[0], pt[1], pt[2], pt[3] };
 	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
 	const uint32_t nextBase = L.nodeBase + n;
@@ -654,91 +743,54 @@ __global__ __launch_bounds__( TB ) void k_children( BuildState *st, int depth, N
 			info[L.nodeBase + i] = make_uint2( L.leafBase + ex[2], ( cnt << 2 ) | 3u );
 			continue;
 		}
-		const float *b = T.box + 6ull * i;
+		float b[6], bl[6], br[6];
+		for ( int k = 0; k < 6; ++k )
+			bl[k] = br[k] = b[k] = T.box[6ull * i + k];
 		const int ax = (int) ( ( kd >> 1 ) & 3u );
 		const float sep = T.sep[i];
 		const uint32_t c = 2u * ex[0];
-		float *bl = N.box + 6ull * c, *br = bl + 6;
-		for ( int k = 0; k < 6; ++k )
-			bl[k] = br[k] = b[k];
 		bl[ax] = 0.5f * ( box_c( b, ax ) - box_e( b, ax ) + sep );
 		bl[3 + ax] = 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) );
 		br[ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep );
 		br[3 + ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep );
+		for ( int k = 0; k < 6; ++k )
+		{
+			N.box[6ull * c + k] = bl[k];
+			N.box[6ull * c + 6 + k] = br[k];
+		}
 		N.start[c] = ex[1];
 		N.count[c] = cl;
 		N.start[c + 1] = ex[1] + cl;
 		N.count[c + 1] = cr;
-		decide_node( N, c, depth + 1, maxDepth, maxPrims );
-		decide_node( N, c + 1u, depth + 1, maxDepth, maxPrims );
+		N.parent[c] = N.parent[c + 1] = i;
+		decide_node( N, c, bl, cl, depth + 1, maxDepth, maxPrims );
+		decide_node( N, c + 1u, br, cr, depth + 1, maxDepth, maxPrims );
 		info[L.nodeBase + i] = make_uint2( __float_as_uint( sep ), ( ( nextBase + c ) << 2 ) | (uint32_t) ax );
 	}
-}
-
-// does reference j go to the left / right child of its node (min < sep / max > sep, :971-1029)
-struct RefSide
-{
-	uint32_t node, kind, tri;
-	bool left, right;
-};
-
-__device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, const uint32_t *refNode, const float *ext, uint32_t nT, uint32_t j )
-{
-	RefSide r;
-	r.node = refNode[j];
-	r.kind = T.kind[r.node];
-	r.tri = refs[j];
-	r.left = r.right = false;
-	if ( r.kind & K_SPLIT )
-	{
-		const uint32_t ax = ( r.kind >> 1 ) & 3u;
-		const float sep = T.sep[r.node];
-		r.left = ext[(size_t) ax * nT + r.tri] < sep;
-		r.right = ext[( 3ull + ax ) * nT + r.tri] > sep;
-	}
-	return r;
-}
-
-// references going left / right in every block's share of the level (the first step of the partition's scan)
-__global__ __launch_bounds__( TB ) void k_count( const BuildState *st, int depth, NodeTab T, const uint32_t *refs, const uint32_t *refNode,
-	const float *ext, uint32_t nT, uint2 *blockSums )
-{
-	if ( st->overflow != OVF_NONE )
-		return;
-	const uint32_t n = st->lv[depth].refs;
-	if ( n == 0u )
-		return;
-	__shared__ uint32_t red[( TB / 64 ) * 2];
-	uint32_t b0, b1;
-	block_range( n, b0, b1 );
-	uint32_t acc[2] = { 0u, 0u };
-	for ( uint32_t j = b0 + threadIdx.x; j < b1; j += TB )
-	{
-		const RefSide r = ref_side( T, refs, refNode, ext, nT, j );
-		acc[0] += r.left ? 1u : 0u;
-		acc[1] += r.right ? 1u : 0u;
-	}
-	block_sum( acc, red );
-	if ( threadIdx.x == 0 )
-		blockSums[blockIdx.x] = make_uint2( acc[0], acc[1] );
 }
 
 // Stable partition (:971-1029): the k-th reference of a node that goes left becomes the k-th reference of its left
 // child; references of leaves move to the leaf pool.  A reference's rank among those of its node that go left is its
 // rank among all of the level that go left, less the left counts of the nodes before its own (NodeTab::excl).
-__global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int depth, NodeTab T, const uint32_t *refs, const uint32_t *refNode,
+// A reference that goes to a child is counted against that child's planes on the way (the children of the nodes of a
+// tile are neighbours in the next level's table N: the same LDS histograms and in-tile splits as in k_hist, a child
+// being complete when its parent's references all lie in the tile), so the next level starts with its counts taken.
+__global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int depth, NodeTab T, NodeTab N, const uint32_t *refs, const uint32_t *refNode,
 	const float *ext, uint32_t nT, const uint2 *blockSums, uint32_t *nextRefs, uint32_t *nextRefNode, uint32_t *leafPool,
-	uint32_t *lostInPlane )
+	uint32_t *hist, uint32_t *lostInPlane )
 {
 	if ( st->overflow != OVF_NONE )
 		return;
 	const LevelState L = st->lv[depth];
 	uint32_t b0, b1;
-	block_range( L.refs, b0, b1 );
+	ref_share( L, gridDim.x, blockIdx.x, b0, b1 );
 	if ( b0 >= b1 )
 		return;
 	__shared__ uint32_t red[( TB / 64 ) * 2];
 	__shared__ uint32_t waveTot[( TB / 64 ) * 2];
+	__shared__ uint32_t sh[HSLOTS * HIST];
+	for ( int k = threadIdx.x; k < HSLOTS * HIST; k += TB )
+		sh[k] = 0u;
 	uint32_t run[2] = { 0u, 0u };
 	for ( uint32_t b = threadIdx.x; b < blockIdx.x; b += TB )
 	{
@@ -751,20 +803,23 @@ __global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int dep
 	const unsigned long long below = ( 1ull << lane ) - 1ull;
 	for ( uint32_t j0 = b0; j0 < b1; j0 += TB )
 	{
+		const uint32_t tileEnd = j0 + TB < b1 ? j0 + TB : b1;
+		const uint32_t node0 = refNode[j0], nodeLast = refNode[tileEnd - 1u];
 		const uint32_t j = j0 + threadIdx.x;
-		const bool valid = j < b1;
+		const bool valid = j < tileEnd;
 		RefSide r;
 		r.node = r.kind = r.tri = 0u;
 		r.left = r.right = false;
 		if ( valid )
 			r = ref_side( T, refs, refNode, ext, nT, j );
 		const unsigned long long mL = __ballot( r.left ), mR = __ballot( r.right );
-		__syncthreads();          // (the previous tile's wave totals have been read)
 		if ( lane == 0u )
 		{
 			waveTot[w * 2] = (uint32_t) __popcll( mL );
 			waveTot[w * 2 + 1] = (uint32_t) __popcll( mR );
 		}
+		const uint32_t kd0 = T.kind[node0], kdLast = T.kind[nodeLast];
+		const uint32_t c0 = 2u * T.excl[node0].x, cEnd = 2u * ( T.excl[nodeLast].x + ( kdLast & K_SPLIT ) );
 		__syncthreads();
 		uint32_t gl = run[0], gr = run[1];
 		for ( uint32_t q = 0; q < TB / 64; ++q )
@@ -776,29 +831,43 @@ __global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int dep
 		}
 		gl += (uint32_t) __popcll( mL & below );
 		gr += (uint32_t) __popcll( mR & below );
-		if ( !valid )
-			continue;
-		const uint4 ex = T.excl[r.node];
-		if ( !( r.kind & K_SPLIT ) )
+		if ( valid )
 		{
-			leafPool[L.leafBase + ex.z + ( j - T.start[r.node] )] = r.tri;
-			continue;
+			const uint4 ex = T.excl[r.node];
+			if ( !( r.kind & K_SPLIT ) )
+				leafPool[L.leafBase + ex.z + ( j - T.start[r.node] )] = r.tri;
+			else
+			{
+				const uint32_t c = 2u * ex.x;
+				if ( !r.left && !r.right )
+					atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
+				if ( r.left )
+				{
+					const uint32_t p = ex.y + ( gl - ex.w );
+					nextRefs[p] = r.tri;
+					nextRefNode[p] = c;
+					const uint32_t kdc = N.kind[c];
+					if ( kdc & K_SPLIT )
+						hist_add( N, c, kdc, r.tri, ext, nT, c0, sh, hist );
+				}
+				if ( r.right )
+				{
+					const uint32_t p = ex.y + T.cntL[r.node] + ( gr - ( ex.y - ex.w ) );
+					nextRefs[p] = r.tri;
+					nextRefNode[p] = c + 1u;
+					const uint32_t kdc = N.kind[c + 1u];
+					if ( kdc & K_SPLIT )
+						hist_add( N, c + 1u, kdc, r.tri, ext, nT, c0, sh, hist );
+				}
+			}
 		}
-		const uint32_t c = 2u * ex.x;
-		if ( !r.left && !r.right )
-			atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
-		if ( r.left )
-		{
-			const uint32_t p = ex.y + ( gl - ex.w );
-			nextRefs[p] = r.tri;
-			nextRefNode[p] = c;
-		}
-		if ( r.right )
-		{
-			const uint32_t p = ex.y + T.cntL[r.node] + ( gr - ( ex.y - ex.w ) );
-			nextRefs[p] = r.tri;
-			nextRefNode[p] = c + 1u;
-		}
+		__syncthreads();
+		// (the first node of the tile goes on in the next one: its two children keep their counts in LDS)
+		const uint32_t keep = tileEnd < b1 && refNode[tileEnd] == node0 && ( kd0 & K_SPLIT ) ? 2u : 0u;
+		const uint32_t span = cEnd - c0;
+		finish_slots( N, c0, span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS, keep, sh, hist,
+			[&]( uint32_t cn ) { const uint32_t par = N.parent[cn], first = T.start[par]; return first >= j0 && first + T.count[par] <= tileEnd; } );
+		__syncthreads();
 	}
 }
 
@@ -1050,12 +1119,13 @@ thread_local int g_scratchDev = -1;
 // carve a level's node table out of one allocation
 int node_tab( DVec &buf, size_t n, hipStream_t s, NodeTab &t )
 {
-	if ( int rc = buf.reserve( n * 18 * sizeof( uint32_t ), s ) ) return rc;
+	if ( int rc = buf.reserve( n * NODE_TAB_WORDS * sizeof( uint32_t ), s ) ) return rc;
 	uint32_t *p = buf.as<uint32_t>();
 	t.excl = (uint4 *) p; p += 4 * n;          // first: 16-byte aligned
 	t.box = (float *) p; p += 6 * n;
 	t.start = p; p += n;
 	t.count = p; p += n;
+	t.parent = p; p += n;
 	t.kind = p; p += n;
 	t.mn = (float *) p; p += n;
 	t.delta = (float *) p; p += n;
@@ -1136,6 +1206,9 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		g_scratch.release();
 		g_scratchDev = dev;
 	}
+	const bool TT = getenv( "RT_KD_TIMING" ) != nullptr;
+	auto t0_ = std::chrono::steady_clock::now();
+	auto stamp = [&]( const char *what ) { if ( TT ) { fprintf( stderr, "  %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>( std::chrono::steady_clock::now() - t0_ ).count() ); } };
 	Scratch &S = g_scratch;
 	if ( !S.pinned )
 		GCHK( hipHostMalloc( &S.pinned, sizeof( BuildState ) + sizeof( GeomInfo ), hipHostMallocDefault ) );
@@ -1149,14 +1222,16 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 	if ( int rc = S.tris.reserve( sizeof( rt_triangle ) * ( nT ? nT : 1 ), s ) ) return rc;
 	if ( vertexCount ) GCHK( hipMemcpyAsync( S.verts.p, verts, sizeof( rt_vertex ) * vertexCount, hipMemcpyHostToDevice, s ) );
 	if ( nT ) GCHK( hipMemcpyAsync( S.tris.p, tris, sizeof( rt_triangle ) * nT, hipMemcpyHostToDevice, s ) );
+	stamp( "input copies enqueued" );
+	if ( TT ) { (void) hipStreamSynchronize( s ); stamp( "input copies done" ); }
 	if ( int rc = S.ext.reserve( 6 * sizeof( float ) * ( nT ? nT : 1 ), s ) ) return rc;
 	if ( int rc = S.geom.reserve( sizeof( GeomInfo ) + 6 * sizeof( float ) * BOX_BLOCKS, s ) ) return rc;
 	if ( int rc = S.state.reserve( sizeof( BuildState ), s ) ) return rc;
-	if ( int rc = S.sums.reserve( sizeof( uint4 ) * G_NODE + sizeof( uint2 ) * G_REF, s ) ) return rc;
+	if ( int rc = S.sums.reserve( sizeof( uint4 ) * G_NODE * SPLIT_FINER + sizeof( uint2 ) * G_REF, s ) ) return rc;
 	GeomInfo *dGeom = S.geom.as<GeomInfo>();
 	BuildState *dState = S.state.as<BuildState>();
 	uint4 *nodeSums = S.sums.as<uint4>();
-	uint2 *refSums = (uint2 *) ( nodeSums + G_NODE );
+	uint2 *refSums = (uint2 *) ( nodeSums + G_NODE * SPLIT_FINER );
 	float *boxPart = (float *) ( dGeom + 1 );
 	GCHK( hipMemsetAsync( dGeom, 0, sizeof( GeomInfo ), s ) );
 	if ( nT ) LAUNCH( k_extents, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
@@ -1209,23 +1284,21 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 			const NodeTab &cur = tab[depth & 1], &next = tab[( depth + 1 ) & 1];
 			const uint32_t *refs = refBuf[depth & 1], *refNode = refs + caps.refs;
 			uint32_t *nRefs = refBuf[( depth + 1 ) & 1], *nRefNode = nRefs + caps.refs;
+			if ( nT && depth == 0 )
+				LAUNCH( k_hist, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), refs, refNode, S.ext.as<float>(), nT );
+			LAUNCH( k_split, dim3( G_NODE * SPLIT_FINER ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), nodeSums );
+			LAUNCH( k_children_count, dim3( G_NODE + ( nT ? G_REF : 0 ) ), dim3( TB ), 0, s, dState, depth, cur, next, nodeSums, S.info.as<uint2>(), caps,
+				maxDepth, maxPrims, refs, refNode, S.ext.as<float>(), nT, refSums );
 			if ( nT )
-				LAUNCH( k_hist, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), refs, refNode,
-					S.ext.as<float>(), nT );
-			LAUNCH( k_split, dim3( G_NODE ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), nodeSums );
-			LAUNCH( k_children, dim3( G_NODE ), dim3( TB ), 0, s, dState, depth, cur, next, nodeSums, S.info.as<uint2>(), caps,
-				maxDepth, maxPrims );
-			if ( nT )
-			{
-				LAUNCH( k_count, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, refs, refNode, S.ext.as<float>(), nT, refSums );
-				LAUNCH( k_scatter, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, refs, refNode, S.ext.as<float>(), nT, refSums,
-					nRefs, nRefNode, S.leafPool.as<uint32_t>(), &dGeom->lostInPlane );
-			}
+				LAUNCH( k_scatter, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, next, refs, refNode, S.ext.as<float>(), nT, refSums,
+					nRefs, nRefNode, S.leafPool.as<uint32_t>(), S.hist.as<uint32_t>(), &dGeom->lostInPlane );
 		}
+		stamp( "levels enqueued" );
 		GCHK( hipMemcpyAsync( hState, dState, sizeof( BuildState ), hipMemcpyDeviceToHost, s ) );
 		GCHK( hipMemcpyAsync( hGeom, dGeom, sizeof( GeomInfo ), hipMemcpyDeviceToHost, s ) );
 		GCHK( hipGetLastError() );
 		GCHK( hipStreamSynchronize( s ) );
+		stamp( "levels done" );
 		S.histClean = true;
 		if ( hGeom->badIndex )
 			return 3;
@@ -1289,6 +1362,7 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 			return 10;
 		}
 	}
+	stamp( "outputs allocated" );
 	if ( int rc = S.order.reserve( sizeof( uint32_t ) * ( (size_t) nRecs + 1 ), s ) ) { rt_kdtree_device_release( out ); return rc; }
 	LAUNCH_OR( rt_kdtree_device_release( out ), k_emit, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, info, nNodes, pos, refPos, S.leafPool.as<uint32_t>(),
 		(rt_hip_kdnode *) out->nodes, S.order.as<uint32_t>() );
@@ -1315,6 +1389,7 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		rt_kdtree_device_release( out );
 		return 10;
 	}
+	stamp( "done" );
 	out->nNodes = nNodes;
 	out->nRecs = nRecs;
 	out->nRecsFull = twoLists ? nRecs : 0;
