@@ -91,7 +91,9 @@ struct GeomInfo
 	uint32_t lostInPlane;  // references that went to neither child of a split (triangles lying in the split plane)
 };
 
-// Extents of every triangle; the index check and the highest material slot ride
+// Extents of every triangle (one array per axis and bound: references that are neighbours in a node's list are mostly
+// neighbours in triangle order, and their loads share cache lines; six floats side by side per triangle made the
+// partition twice as slow); the index check and the highest material slot ride
 // along (the triangles are read here anyway). A triangle with a bad index gets
 // no extents and raises the flag: the host gives up before anything else reads it.
 __global__ __launch_bounds__( TB ) void k_extents( const rt_vertex *verts, const rt_triangle *tris, uint32_t nT, uint64_t nV, float *ext,
@@ -241,6 +243,9 @@ struct BuildState
 	uint32_t overflow;          // OVF_*
 	uint32_t need;              // the count that did not fit
 	uint32_t nLevels, nodesTotal, leafRefs;     // written by the level that splits nothing
+	uint32_t nLong;             // leaves of more than 32 references met by k_emit
+	uint32_t rootDepth;         // depth of the finished tree
+	uint32_t fits;              // the tree is complete and fits the buffers the result is written to (k_fit)
 };
 
 struct Caps { uint32_t refs, levelNodes, nodesTotal, leaf; };
@@ -250,7 +255,13 @@ enum : uint32_t { K_SPLIT = 1u, K_SORTED = 8u, K_DONE = 16u };     // (bits 1-2:
 
 struct NodeTab
 {
-	uint4 *excl;           // over the nodes before this one: x inner nodes, y references handed to children, z references in leaves, w references handed to left children
+	// What the partition needs of a node, fetched by every reference of the node in one go (written by k_children_count):
+	//   [0] over the nodes before this one: x inner nodes, y references handed to children, z references in leaves, w references handed to left children
+	//   [1] kind, chosen plane, references going left, first reference
+	//   [2] references, kind of the left / right child
+	//   [3] first candidate plane and plane distance of the left child, of the right child
+	//   [4], [5] what the SAH sweep needs of the left / right child's box (SahBox: c, e, eA, eB)
+	uint4 *rec;
 	float *box;            // [6 * n]: centre xyz, half extent xyz
 	uint32_t *start, *count;
 	uint32_t *parent;      // index in the level above
@@ -259,16 +270,26 @@ struct NodeTab
 	float *sep;            // chosen plane
 	uint32_t *cntL, *cntR;
 };
-constexpr int NODE_TAB_WORDS = 4 + 6 + 9;
+constexpr int REC = 6;                   // uint4 per node record
+constexpr int NODE_TAB_WORDS = 4 * REC + 6 + 9;
 
 constexpr int HIST = 2 * PARTS + 2;      // per node: left histogram [33], right histogram [33] (sorted planes); else L[32], R[32] at 0 and 33
 constexpr int HSLOTS = 64;               // nodes of one tile of references counted in LDS
 constexpr int G_REF = 4096, G_NODE = 256;  // blocks of the per-reference / per-node part of a launch
+constexpr int RPT = 1, TILE = RPT * TB;  // the partition: references per thread, per tile
 constexpr int SPLIT_FINER = 8;           // k_split's blocks take an eighth of a k_children block's nodes each
 static_assert( PARTS == 32, "the split search gives one plane to each lane of half a wave" );
 
-__device__ inline float box_c( const float *b, int ax ) { return b[ax]; }
-__device__ inline float box_e( const float *b, int ax ) { return b[3 + ax]; }
+// A node's box by value (named members, picked by comparing the axis: an array indexed by the axis lives in scratch memory)
+struct Box
+{
+	float cx, cy, cz, ex, ey, ez;      // centre, half extent
+};
+__device__ inline Box load_box( const float *b ) { return Box{ b[0], b[1], b[2], b[3], b[4], b[5] }; }
+__device__ inline void store_box( float *b, const Box &v ) { b[0] = v.cx; b[1] = v.cy; b[2] = v.cz; b[3] = v.ex; b[4] = v.ey; b[5] = v.ez; }
+__device__ inline float pick3( int ax, float x, float y, float z ) { float r = x; if ( ax == 1 ) r = y; if ( ax == 2 ) r = z; return r; }
+__device__ inline float box_c( const Box &b, int ax ) { return pick3( ax, b.cx, b.cy, b.cz ); }
+__device__ inline float box_e( const Box &b, int ax ) { return pick3( ax, b.ex, b.ey, b.ez ); }
 
 // contiguous share of n nodes for block blk of nBlocks, a multiple of TB long
 __device__ inline uint32_t node_share( uint32_t n, uint32_t nBlocks ) { return ( ( n + nBlocks * TB - 1u ) / ( nBlocks * TB ) ) * TB; }
@@ -280,16 +301,16 @@ __device__ inline void share_of( uint32_t n, uint32_t per, uint32_t blk, uint32_
 	b1 = s + per < n ? (uint32_t) ( s + per ) : n;
 }
 
-// Contiguous share of a level's references for block blk of nBlocks, in tiles of TB.  Near the root a node holds so
+// Contiguous share of a level's references for block blk of nBlocks, in tiles of `tile`.  Near the root a node holds so
 // many references that its counts would be flushed by thousands of blocks, one atomic after the other on the same 66
 // words: there a block takes more tiles (it keeps the counts of a node in LDS from tile to tile), so that a node
 // is shared by about 512 blocks at most.
-__device__ inline void ref_share( const LevelState &L, uint32_t nBlocks, uint32_t blk, uint32_t &b0, uint32_t &b1 )
+__device__ inline void ref_share( const LevelState &L, uint32_t nBlocks, uint32_t blk, uint32_t tile, uint32_t &b0, uint32_t &b1 )
 {
-	uint32_t tiles = ( L.refs + nBlocks * TB - 1u ) / ( nBlocks * TB );
-	const uint32_t perNode = L.refs / ( L.nodes ? L.nodes : 1u ) / ( 512u * TB );
+	uint32_t tiles = ( L.refs + nBlocks * tile - 1u ) / ( nBlocks * tile );
+	const uint32_t perNode = L.refs / ( L.nodes ? L.nodes : 1u ) / ( 512u * tile );
 	if ( tiles < perNode ) tiles = perNode;
-	share_of( L.refs, tiles * TB, blk, b0, b1 );
+	share_of( L.refs, tiles * tile, blk, b0, b1 );
 }
 
 __device__ inline uint32_t wave_sum( uint32_t v )
@@ -321,17 +342,24 @@ __device__ inline void block_sum( uint32_t ( &v )[N], uint32_t *red )
 
 // leaf (count <= maxPrims or depth == maxDepth) or inner node with its split axis:
 // longest half extent, ties X > Y > Z (:945-957), and the candidate planes
-__device__ inline void decide_node( const NodeTab &T, uint32_t i, const float *b, uint32_t cnt, int depth, int maxDepth, int maxPrims )
+struct Decision
 {
+	uint32_t kind;
+	float mn, delta;
+};
+
+__device__ __forceinline__ Decision decide_node( const NodeTab &T, uint32_t i, const Box &b, uint32_t cnt, int depth, int maxDepth, int maxPrims )
+{
+	Decision d = { 0u, 0.0f, 0.0f };
 	if ( cnt <= (uint32_t) maxPrims || depth == maxDepth )
 	{
 		T.kind[i] = 0u;
-		return;
+		return d;
 	}
-	float range = b[3];
+	float range = b.ex;
 	int ax = 0;
-	if ( range < b[4] ) { range = b[4]; ax = 1; }
-	if ( range < b[5] ) { range = b[5]; ax = 2; }
+	if ( range < b.ey ) { range = b.ey; ax = 1; }
+	if ( range < b.ez ) { range = b.ez; ax = 2; }
 	const float c = box_c( b, ax ), e = box_e( b, ax );
 	const float mn = c - e, mx = c + e;
 	const float delta = ( mx - mn ) / (float) PARTS;
@@ -343,9 +371,13 @@ __device__ inline void decide_node( const NodeTab &T, uint32_t i, const float *b
 		if ( k && !( prev <= s ) ) sorted = false;
 		prev = s;
 	}
-	T.kind[i] = K_SPLIT | ( (uint32_t) ax << 1 ) | ( sorted ? K_SORTED : 0u );
+	d.kind = K_SPLIT | ( (uint32_t) ax << 1 ) | ( sorted ? K_SORTED : 0u );
+	d.mn = mn;
+	d.delta = delta;
+	T.kind[i] = d.kind;
 	T.mn[i] = mn;
 	T.delta[i] = delta;
+	return d;
 }
 
 // the root and the state of level 0 (the state has been zeroed: a level that was never reached holds nothing)
@@ -353,9 +385,8 @@ __global__ __launch_bounds__( 64 ) void k_root( BuildState *st, NodeTab T, const
 {
 	if ( threadIdx.x != 0 )
 		return;
-	float b[6];
-	for ( int k = 0; k < 6; ++k )
-		T.box[k] = b[k] = geom->box[k];
+	const Box b = load_box( geom->box );
+	store_box( T.box, b );
 	T.start[0] = 0u;
 	T.count[0] = nT;
 	T.parent[0] = 0u;
@@ -364,19 +395,38 @@ __global__ __launch_bounds__( 64 ) void k_root( BuildState *st, NodeTab T, const
 	st->lv[0].refs = nT;
 }
 
+// what the SAH sweep needs to know of a node's box
+struct SahBox
+{
+	float c, e;            // centre and half extent along the split axis
+	float eA, eB;          // half extents along the other two
+	float mn, delta;
+};
+
+__device__ __forceinline__ SahBox sah_box( const Box &b, uint32_t kd, float mn, float delta )
+{
+	const int ax = (int) ( ( kd >> 1 ) & 3u );
+	SahBox s;
+	s.c = box_c( b, ax );
+	s.e = box_e( b, ax );
+	s.eA = pick3( ax, b.ey, b.ex, b.ex );
+	s.eB = pick3( ax, b.ez, b.ez, b.ey );
+	s.mn = mn;
+	s.delta = delta;
+	return s;
+}
+
+__device__ inline SahBox sah_box( const NodeTab &T, uint32_t i, uint32_t kd )
+{
+	return sah_box( load_box( T.box + 6ull * i ), kd, T.mn[i], T.delta[i] );
+}
+
 // SAH sweep of :591-857 on the counts of one node, by 32 lanes (lane l = plane l):
 // the lowest index with the strictly smallest cost.  h: the node's histogram (LDS or HBM).
-__device__ inline void sah_node( const NodeTab &T, uint32_t i, uint32_t kd, const uint32_t *h, uint32_t l )
+__device__ inline void sah_node( const NodeTab &T, uint32_t i, uint32_t kd, const SahBox &B, const uint32_t *h, uint32_t l )
 {
-	const float *b = T.box + 6ull * i;
-	const int ax = (int) ( ( kd >> 1 ) & 3u );
 	const bool sorted = ( kd & K_SORTED ) != 0u;
-	const float c = box_c( b, ax ), e = box_e( b, ax );
-	const float mn = T.mn[i], delta = T.delta[i];
-	float eA, eB;
-	if ( ax == 0 ) { eA = b[4]; eB = b[5]; }
-	else if ( ax == 1 ) { eA = b[3]; eB = b[5]; }
-	else { eA = b[3]; eB = b[4]; }
+	const float c = B.c, e = B.e, mn = B.mn, delta = B.delta, eA = B.eA, eB = B.eB;
 	const float area = eA * eB;
 	// sorted planes: L[k] = histL[0 .. k], R[k] = histR[k + 1 .. 32]; else the counts themselves
 	uint32_t Lk = h[l], Rk = sorted ? h[33u + l + 1u] : h[33u + l];
@@ -416,14 +466,18 @@ __device__ inline void hist_clear( uint32_t *h, uint32_t l )
 	if ( l < 2u ) h[64u + l] = 0u;
 }
 
-// One triangle extent [a, b] against the 32 planes of node i of table T: into the node's slot of the LDS histograms
+// One triangle's extent [a, b] along the axis of node i against the node's 32 planes mn + k * delta: into the node's slot of the LDS histograms
 // when it has one (slot = node index - first node of the tile), else into its histogram in HBM.
-__device__ inline void hist_add( const NodeTab &T, uint32_t i, uint32_t kd, uint32_t tri, const float *ext, uint32_t nT, uint32_t first,
-	uint32_t *sh, uint32_t *hist )
+struct Ext
 {
-	const uint32_t ax = ( kd >> 1 ) & 3u;
-	const float a = ext[(size_t) ax * nT + tri], b = ext[( 3ull + ax ) * nT + tri];
-	const float mn = T.mn[i], delta = T.delta[i];
+	const float *p;
+	uint32_t nT;
+	__device__ float lo( uint32_t ax, uint32_t tri ) const { return p[(size_t) ax * nT + tri]; }
+	__device__ float hi( uint32_t ax, uint32_t tri ) const { return p[( 3ull + ax ) * nT + tri]; }
+};
+
+__device__ inline void hist_add( uint32_t i, uint32_t kd, float mn, float delta, float a, float b, uint32_t first, uint32_t *sh, uint32_t *hist )
+{
 	const uint32_t slot = i - first;
 	const bool inLds = slot < (uint32_t) HSLOTS;
 	uint32_t *hl = sh + ( inLds ? slot : 0u ) * HIST, *hg = hist + (size_t) HIST * i;
@@ -452,26 +506,54 @@ __device__ inline void hist_add( const NodeTab &T, uint32_t i, uint32_t kd, uint
 	}
 }
 
-// After a tile of references has been counted: half a wave per node that has a slot in LDS (nodes first ..
-// first + nSlots - 1 of table T).  A node all of whose references were in this tile gets its split chosen right
-// here and never touches the histograms in HBM; the first `keep` slots stay as they are (their nodes go on in the
-// next tile); the counts of the others are added to theirs in HBM.
+// what finish_slots knows of the node in a slot
+struct SlotFacts
+{
+	uint32_t kind;         // 0: nothing to do; K_DONE set here: all its references were in this tile
+	SahBox box;
+};
+
+// One thread per slot: what finish_slots needs of the nodes first .. first + nSlots - 1 of table T
+// (complete( i ): all references of node i were in this tile).
 template <class Complete>
-__device__ inline void finish_slots( const NodeTab &T, uint32_t first, uint32_t nSlots, uint32_t keep, uint32_t *sh, uint32_t *hist, Complete complete )
+__device__ inline void gather_facts( const NodeTab &T, uint32_t first, uint32_t nSlots, SlotFacts *facts, Complete complete )
+{
+	if ( threadIdx.x < nSlots )
+	{
+		const uint32_t i = first + threadIdx.x, kd = T.kind[i];
+		uint32_t fk = 0u;
+		if ( kd & K_SPLIT )
+		{
+			fk = kd;
+			if ( complete( i ) )
+			{
+				fk = kd | K_DONE;
+				facts[threadIdx.x].box = sah_box( T, i, kd );
+				T.kind[i] = fk;
+			}
+		}
+		facts[threadIdx.x].kind = fk;
+	}
+}
+
+// After a tile of references has been counted and the block has met: the nodes that have a slot in LDS (nodes
+// first .. first + nSlots - 1 of table T, facts[] filled in).  A node all of whose references were in this tile gets
+// its split chosen right here, by half a wave, and never touches the histograms in HBM; the first `keep` slots stay
+// as they are (their nodes go on in the next tile); the counts of the others are added to theirs in HBM.  The facts
+// are left cleared.
+__device__ inline void finish_slots( const NodeTab &T, uint32_t first, uint32_t nSlots, uint32_t keep, uint32_t *sh, uint32_t *hist, SlotFacts *facts )
 {
 	const uint32_t l = threadIdx.x & 31u;
 	for ( uint32_t s = threadIdx.x >> 5; s < nSlots; s += TB / 32 )
 	{
-		const uint32_t i = first + s, kd = T.kind[i];
+		const uint32_t i = first + s, kd = facts[s].kind;
 		if ( !( kd & K_SPLIT ) )
 			continue;
 		uint32_t *h = sh + s * HIST;
-		if ( complete( i ) )
+		if ( kd & K_DONE )
 		{
-			sah_node( T, i, kd, h, l );
+			sah_node( T, i, kd, facts[s].box, h, l );
 			hist_clear( h, l );
-			if ( l == 0u )
-				T.kind[i] = kd | K_DONE;
 		}
 		else if ( s >= keep )
 		{
@@ -486,6 +568,8 @@ __device__ inline void finish_slots( const NodeTab &T, uint32_t first, uint32_t 
 				}
 			}
 		}
+		if ( l == 0u )
+			facts[s].kind = 0u;
 	}
 }
 
@@ -493,16 +577,17 @@ __device__ inline void finish_slots( const NodeTab &T, uint32_t first, uint32_t 
 // partition counts for the level it fills, k_scatter).  References are ordered by node, a block takes a contiguous
 // run of them in tiles of TB; the nodes a tile touches are counted in LDS (the first HSLOTS of them).
 __global__ __launch_bounds__( TB ) void k_hist( const BuildState *st, int depth, NodeTab T, uint32_t *hist, const uint32_t *refs,
-	const uint32_t *refNode, const float *ext, uint32_t nT )
+	const uint32_t *refNode, Ext ext )
 {
 	if ( st->overflow != OVF_NONE )
 		return;
 	const LevelState L = st->lv[depth];
 	uint32_t b0, b1;
-	ref_share( L, gridDim.x, blockIdx.x, b0, b1 );
+	ref_share( L, gridDim.x, blockIdx.x, TB, b0, b1 );
 	if ( b0 >= b1 )
 		return;
 	__shared__ uint32_t sh[HSLOTS * HIST];
+	__shared__ SlotFacts facts[HSLOTS];
 	for ( int k = threadIdx.x; k < HSLOTS * HIST; k += TB )
 		sh[k] = 0u;
 	__syncthreads();
@@ -515,13 +600,18 @@ __global__ __launch_bounds__( TB ) void k_hist( const BuildState *st, int depth,
 		{
 			const uint32_t i = refNode[j], kd = T.kind[i];
 			if ( kd & K_SPLIT )
-				hist_add( T, i, kd, refs[j], ext, nT, node0, sh, hist );
+			{
+				const uint32_t tri = refs[j], ax = ( kd >> 1 ) & 3u;
+				hist_add( i, kd, T.mn[i], T.delta[i], ext.lo( ax, tri ), ext.hi( ax, tri ), node0, sh, hist );
+			}
 		}
 		__syncthreads();
 		const uint32_t keep = tileEnd < b1 && refNode[tileEnd] == node0 ? 1u : 0u;
 		const uint32_t span = nodeLast - node0 + 1u;
-		finish_slots( T, node0, span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS, keep, sh, hist,
-			[&]( uint32_t i ) { const uint32_t first = T.start[i]; return first >= j0 && first + T.count[i] <= tileEnd; } );
+		const uint32_t nSlots = span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS;
+		gather_facts( T, node0, nSlots, facts, [&]( uint32_t i ) { const uint32_t first = T.start[i]; return first >= j0 && first + T.count[i] <= tileEnd; } );
+		__syncthreads();
+		finish_slots( T, node0, nSlots, keep, sh, hist, facts );
 		__syncthreads();
 	}
 }
@@ -561,7 +651,8 @@ __global__ __launch_bounds__( TB ) void k_split( const BuildState *st, int depth
 		{
 			const uint32_t ni = todo[q];
 			uint32_t *h = hist + (size_t) HIST * ni;
-			sah_node( T, ni, T.kind[ni], h, l );
+			const uint32_t kdn = T.kind[ni];
+			sah_node( T, ni, kdn, sah_box( T, ni, kdn ), h, l );
 			hist_clear( h, l );
 		}
 		__syncthreads();
@@ -590,7 +681,7 @@ struct RefSide
 	bool left, right;
 };
 
-__device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, const uint32_t *refNode, const float *ext, uint32_t nT, uint32_t j )
+__device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, const uint32_t *refNode, const Ext &ext, uint32_t j )
 {
 	RefSide r;
 	r.node = refNode[j];
@@ -601,10 +692,32 @@ __device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, cons
 	{
 		const uint32_t ax = ( r.kind >> 1 ) & 3u;
 		const float sep = T.sep[r.node];
-		r.left = ext[(size_t) ax * nT + r.tri] < sep;
-		r.right = ext[( 3ull + ax ) * nT + r.tri] > sep;
+		r.left = ext.lo( ax, r.tri ) < sep;
+		r.right = ext.hi( ax, r.tri ) > sep;
 	}
 	return r;
+}
+
+// what k_children_count reads of a node
+struct NodeFacts
+{
+	uint32_t kd, cnt, cl, cr, start, parent;
+	float sep;
+	Box b;
+};
+
+__device__ __forceinline__ NodeFacts node_facts( const NodeTab &T, uint32_t i )
+{
+	NodeFacts f;
+	f.kd = T.kind[i];
+	f.cnt = T.count[i];
+	f.start = T.start[i];
+	f.parent = T.parent[i];
+	f.cl = T.cntL[i];
+	f.cr = T.cntR[i];
+	f.sep = T.sep[i];
+	f.b = load_box( T.box + 6ull * i );
+	return f;
 }
 
 // Two independent pieces of work in one launch (both need nothing but k_split's results).
@@ -614,8 +727,8 @@ __device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, cons
 // level's totals for itself, so all of them agree whether the next level fits the work buffers.
 // Blocks [G_NODE, G_NODE + G_REF): references going left / right in every block's share of the level (the first
 // step of the partition's scan).
-__global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int depth, NodeTab T, NodeTab N, const uint4 *blockSums, uint2 *info,
-	Caps caps, int maxDepth, int maxPrims, const uint32_t *refs, const uint32_t *refNode, const float *ext, uint32_t nT, uint2 *refSums )
+__global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int depth, NodeTab T, NodeTab N, const uint4 *blockSums, uint2 *info, uint4 *walk,
+	Caps caps, int maxDepth, int maxPrims, const uint32_t *refs, const uint32_t *refNode, Ext ext, uint2 *refSums )
 {
 	if ( st->overflow != OVF_NONE )
 		return;
@@ -628,11 +741,11 @@ __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int de
 	if ( blockIdx.x >= (uint32_t) G_NODE )
 	{
 		uint32_t b0, b1;
-		ref_share( L, G_REF, blockIdx.x - G_NODE, b0, b1 );
+		ref_share( L, G_REF, blockIdx.x - G_NODE, TILE, b0, b1 );
 		uint32_t acc[2] = { 0u, 0u };
 		for ( uint32_t j = b0 + threadIdx.x; j < b1; j += TB )
 		{
-			const RefSide r = ref_side( T, refs, refNode, ext, nT, j );
+			const RefSide r = ref_side( T, refs, refNode, ext, j );
 			acc[0] += r.left ? 1u : 0u;
 			acc[1] += r.right ? 1u : 0u;
 		}
@@ -641,6 +754,12 @@ __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int de
 			refSums[blockIdx.x - G_NODE] = make_uint2( acc[0], acc[1] );
 		return;
 	}
+	uint32_t b0, b1;
+	share_of( n, node_share( n, G_NODE ), blockIdx.x, b0, b1 );
+	// what this thread needs of its node in the block's first tile (the loads are in flight while the sums are formed)
+	NodeFacts f0 = { 0u, 0u, 0u, 0u, 0u, 0u, 0.0f, { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f } };
+	if ( b0 + threadIdx.x < b1 )
+		f0 = node_facts( T, b0 + threadIdx.x );
 	uint32_t pt[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };      // sums of the nodes before this block's, of all nodes
 	for ( uint32_t b = threadIdx.x; b < (uint32_t) ( G_NODE * SPLIT_FINER ); b += TB )
 	{
@@ -682,11 +801,9 @@ __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int de
 	}
 	if ( ovf != OVF_NONE )
 		return;
-	uint32_t b0, b1;
-	share_of( n, node_share( n, G_NODE ), blockIdx.x, b0, b1 );
 	uint32_t run[4] = { pt[0], pt[1], pt[2], pt[3] };
 	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-	const uint32_t nextBase = L.nodeBase + n;
+	const uint32_t nextBase = L.nodeBase + n, parentBase = depth ? st->lv[depth - 1].nodeBase : 0u;
 	for ( uint32_t i0 = b0; i0 < b1; i0 += TB )
 	{
 		const uint32_t i = i0 + threadIdx.x;
@@ -694,12 +811,14 @@ __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int de
 		uint32_t kd = 0u, own[4] = { 0u, 0u, 0u, 0u }, cnt = 0u, cl = 0u, cr = 0u;
 		if ( valid )
 		{
-			kd = T.kind[i];
-			cnt = T.count[i];
+			if ( i0 != b0 )
+				f0 = node_facts( T, i );
+			kd = f0.kd;
+			cnt = f0.cnt;
 			if ( kd & K_SPLIT )
 			{
-				cl = T.cntL[i];
-				cr = T.cntR[i];
+				cl = f0.cl;
+				cr = f0.cr;
 				own[0] = 1u; own[1] = cl + cr; own[3] = cl;
 			}
 			else
@@ -737,60 +856,83 @@ __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int de
 		}
 		if ( !valid )
 			continue;
-		T.excl[i] = make_uint4( ex[0], ex[1], ex[2], ex[3] );
+		uint4 *rec = T.rec + (size_t) REC * i;
+		rec[0] = make_uint4( ex[0], ex[1], ex[2], ex[3] );
+		walk[L.nodeBase + i] = make_uint4( parentBase + f0.parent, ex[0], ex[2], (uint32_t) depth );
 		if ( !( kd & K_SPLIT ) )
 		{
+			rec[1] = make_uint4( 0u, 0u, 0u, f0.start );
+			rec[2] = make_uint4( cnt, 0u, 0u, 0u );
 			info[L.nodeBase + i] = make_uint2( L.leafBase + ex[2], ( cnt << 2 ) | 3u );
 			continue;
 		}
-		float b[6], bl[6], br[6];
-		for ( int k = 0; k < 6; ++k )
-			bl[k] = br[k] = b[k] = T.box[6ull * i + k];
+		const Box b = f0.b;
+		Box bl = b, br = b;
 		const int ax = (int) ( ( kd >> 1 ) & 3u );
-		const float sep = T.sep[i];
+		const float sep = f0.sep;
 		const uint32_t c = 2u * ex[0];
-		bl[ax] = 0.5f * ( box_c( b, ax ) - box_e( b, ax ) + sep );
-		bl[3 + ax] = 0.5f * ( sep - box_c( b, ax ) + box_e( b, ax ) );
-		br[ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) + sep );
-		br[3 + ax] = 0.5f * ( box_c( b, ax ) + box_e( b, ax ) - sep );
-		for ( int k = 0; k < 6; ++k )
 		{
-			N.box[6ull * c + k] = bl[k];
-			N.box[6ull * c + 6 + k] = br[k];
+			const float bc = box_c( b, ax ), be = box_e( b, ax );
+			const float lc = 0.5f * ( bc - be + sep ), le = 0.5f * ( sep - bc + be );
+			const float rc = 0.5f * ( bc + be + sep ), re = 0.5f * ( bc + be - sep );
+			if ( ax == 0 ) { bl.cx = lc; bl.ex = le; br.cx = rc; br.ex = re; }
+			else if ( ax == 1 ) { bl.cy = lc; bl.ey = le; br.cy = rc; br.ey = re; }
+			else { bl.cz = lc; bl.ez = le; br.cz = rc; br.ez = re; }
 		}
+		store_box( N.box + 6ull * c, bl );
+		store_box( N.box + 6ull * c + 6, br );
 		N.start[c] = ex[1];
 		N.count[c] = cl;
 		N.start[c + 1] = ex[1] + cl;
 		N.count[c + 1] = cr;
 		N.parent[c] = N.parent[c + 1] = i;
-		decide_node( N, c, bl, cl, depth + 1, maxDepth, maxPrims );
-		decide_node( N, c + 1u, br, cr, depth + 1, maxDepth, maxPrims );
+		const Decision dl = decide_node( N, c, bl, cl, depth + 1, maxDepth, maxPrims );
+		const Decision dr = decide_node( N, c + 1u, br, cr, depth + 1, maxDepth, maxPrims );
+		rec[1] = make_uint4( kd, __float_as_uint( sep ), cl, f0.start );
+		rec[2] = make_uint4( cnt, dl.kind, dr.kind, 0u );
+		rec[3] = make_uint4( __float_as_uint( dl.mn ), __float_as_uint( dl.delta ), __float_as_uint( dr.mn ), __float_as_uint( dr.delta ) );
+		if ( dl.kind & K_SPLIT )
+		{
+			const SahBox s = sah_box( bl, dl.kind, dl.mn, dl.delta );
+			rec[4] = make_uint4( __float_as_uint( s.c ), __float_as_uint( s.e ), __float_as_uint( s.eA ), __float_as_uint( s.eB ) );
+		}
+		if ( dr.kind & K_SPLIT )
+		{
+			const SahBox s = sah_box( br, dr.kind, dr.mn, dr.delta );
+			rec[5] = make_uint4( __float_as_uint( s.c ), __float_as_uint( s.e ), __float_as_uint( s.eA ), __float_as_uint( s.eB ) );
+		}
 		info[L.nodeBase + i] = make_uint2( __float_as_uint( sep ), ( ( nextBase + c ) << 2 ) | (uint32_t) ax );
 	}
 }
 
 // Stable partition (:971-1029): the k-th reference of a node that goes left becomes the k-th reference of its left
 // child; references of leaves move to the leaf pool.  A reference's rank among those of its node that go left is its
-// rank among all of the level that go left, less the left counts of the nodes before its own (NodeTab::excl).
+// rank among all of the level that go left, less the left counts of the nodes before its own (NodeTab::rec[0]).
 // A reference that goes to a child is counted against that child's planes on the way (the children of the nodes of a
 // tile are neighbours in the next level's table N: the same LDS histograms and in-tile splits as in k_hist, a child
 // being complete when its parent's references all lie in the tile), so the next level starts with its counts taken.
+// The kernel waits for memory most of the time, so a tile is three rounds of loads and no more (reference -> the
+// node's record, which holds all that is needed of the node and of its children -> extents), and a thread has RPT
+// references of the tile under way at once.
 __global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int depth, NodeTab T, NodeTab N, const uint32_t *refs, const uint32_t *refNode,
-	const float *ext, uint32_t nT, const uint2 *blockSums, uint32_t *nextRefs, uint32_t *nextRefNode, uint32_t *leafPool,
+	Ext ext, const uint2 *blockSums, uint32_t *nextRefs, uint32_t *nextRefNode, uint32_t *leafPool,
 	uint32_t *hist, uint32_t *lostInPlane )
 {
 	if ( st->overflow != OVF_NONE )
 		return;
 	const LevelState L = st->lv[depth];
 	uint32_t b0, b1;
-	ref_share( L, gridDim.x, blockIdx.x, b0, b1 );
+	ref_share( L, gridDim.x, blockIdx.x, TILE, b0, b1 );
 	if ( b0 >= b1 )
 		return;
 	__shared__ uint32_t red[( TB / 64 ) * 2];
-	__shared__ uint32_t waveTot[( TB / 64 ) * 2];
+	__shared__ uint32_t waveTot[( TB / 64 ) * RPT * 2];
 	__shared__ uint32_t sh[HSLOTS * HIST];
+	__shared__ SlotFacts facts[HSLOTS];
 	for ( int k = threadIdx.x; k < HSLOTS * HIST; k += TB )
 		sh[k] = 0u;
+	if ( threadIdx.x < HSLOTS )
+		facts[threadIdx.x].kind = 0u;
 	uint32_t run[2] = { 0u, 0u };
 	for ( uint32_t b = threadIdx.x; b < blockIdx.x; b += TB )
 	{
@@ -801,163 +943,304 @@ __global__ __launch_bounds__( TB ) void k_scatter( const BuildState *st, int dep
 	block_sum( run, red );
 	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
 	const unsigned long long below = ( 1ull << lane ) - 1ull;
-	for ( uint32_t j0 = b0; j0 < b1; j0 += TB )
+	for ( uint32_t j0 = b0; j0 < b1; j0 += TILE )
 	{
-		const uint32_t tileEnd = j0 + TB < b1 ? j0 + TB : b1;
+		const uint32_t tileEnd = j0 + TILE < b1 ? j0 + TILE : b1;
 		const uint32_t node0 = refNode[j0], nodeLast = refNode[tileEnd - 1u];
-		const uint32_t j = j0 + threadIdx.x;
-		const bool valid = j < tileEnd;
-		RefSide r;
-		r.node = r.kind = r.tri = 0u;
-		r.left = r.right = false;
-		if ( valid )
-			r = ref_side( T, refs, refNode, ext, nT, j );
-		const unsigned long long mL = __ballot( r.left ), mR = __ballot( r.right );
-		if ( lane == 0u )
+		const uint32_t nodeNext = tileEnd < b1 ? refNode[tileEnd] : 0xffffffffu;
+		const uint32_t kd0 = T.rec[(size_t) REC * node0 + 1].x, kdLast = T.rec[(size_t) REC * nodeLast + 1].x;
+		const uint32_t c0 = 2u * T.rec[(size_t) REC * node0].x, cEnd = 2u * ( T.rec[(size_t) REC * nodeLast].x + ( kdLast & K_SPLIT ) );
+		// (the first node of the tile goes on in the next one: its two children keep their counts in LDS)
+		const uint32_t keep = nodeNext == node0 && ( kd0 & K_SPLIT ) ? 2u : 0u;
+		uint32_t tri[RPT], kind[RPT], cl[RPT], first[RPT];
+		uint4 ex[RPT];
+		bool left[RPT], right[RPT];
+		unsigned long long mL[RPT], mR[RPT];
+		// round 1: the references
+		uint32_t node[RPT];
+		bool speaks[RPT];          // the node's first reference in the tile speaks for the node: what finish_slots needs of its children
+		for ( int u = 0; u < RPT; ++u )
 		{
-			waveTot[w * 2] = (uint32_t) __popcll( mL );
-			waveTot[w * 2 + 1] = (uint32_t) __popcll( mR );
-		}
-		const uint32_t kd0 = T.kind[node0], kdLast = T.kind[nodeLast];
-		const uint32_t c0 = 2u * T.excl[node0].x, cEnd = 2u * ( T.excl[nodeLast].x + ( kdLast & K_SPLIT ) );
-		__syncthreads();
-		uint32_t gl = run[0], gr = run[1];
-		for ( uint32_t q = 0; q < TB / 64; ++q )
-		{
-			const uint32_t tl = waveTot[q * 2], tr = waveTot[q * 2 + 1];
-			if ( q < w ) { gl += tl; gr += tr; }
-			run[0] += tl;
-			run[1] += tr;
-		}
-		gl += (uint32_t) __popcll( mL & below );
-		gr += (uint32_t) __popcll( mR & below );
-		if ( valid )
-		{
-			const uint4 ex = T.excl[r.node];
-			if ( !( r.kind & K_SPLIT ) )
-				leafPool[L.leafBase + ex.z + ( j - T.start[r.node] )] = r.tri;
-			else
+			const uint32_t j = j0 + u * TB + threadIdx.x;
+			node[u] = tri[u] = 0u;
+			speaks[u] = false;
+			if ( j < tileEnd )
 			{
-				const uint32_t c = 2u * ex.x;
-				if ( !r.left && !r.right )
-					atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
-				if ( r.left )
+				node[u] = refNode[j];
+				tri[u] = refs[j];
+				speaks[u] = j == j0 || refNode[j - 1u] != node[u];
+			}
+		}
+		// round 2: their nodes' records
+		uint4 r1[RPT], r2[RPT], r3[RPT];
+		for ( int u = 0; u < RPT; ++u )
+		{
+			const uint4 *rec = T.rec + (size_t) REC * node[u];
+			ex[u] = rec[0];
+			r1[u] = rec[1];
+			r2[u] = rec[2];
+			r3[u] = rec[3];
+		}
+		// round 3: the triangles' extents; the children's boxes where the children get their split right here
+		float pa[RPT], pb[RPT], la[RPT], lb[RPT], ra[RPT], rb[RPT];     // along the axis of the node, of its left, of its right child
+		uint4 bx[RPT][2];
+		bool complete[RPT];
+		for ( int u = 0; u < RPT; ++u )
+		{
+			const uint32_t j = j0 + u * TB + threadIdx.x;
+			kind[u] = j < tileEnd ? r1[u].x : 0u;
+			cl[u] = r1[u].z;
+			first[u] = r1[u].w;
+			pa[u] = pb[u] = la[u] = lb[u] = ra[u] = rb[u] = 0.0f;
+			bx[u][0] = bx[u][1] = make_uint4( 0u, 0u, 0u, 0u );
+			complete[u] = false;
+			if ( kind[u] & K_SPLIT )
+			{
+				const uint32_t ax = ( kind[u] >> 1 ) & 3u, axl = ( r2[u].y >> 1 ) & 3u, axr = ( r2[u].z >> 1 ) & 3u;
+				pa[u] = ext.lo( ax, tri[u] );
+				pb[u] = ext.hi( ax, tri[u] );
+				if ( r2[u].y & K_SPLIT ) { la[u] = ext.lo( axl, tri[u] ); lb[u] = ext.hi( axl, tri[u] ); }
+				if ( r2[u].z & K_SPLIT ) { ra[u] = ext.lo( axr, tri[u] ); rb[u] = ext.hi( axr, tri[u] ); }
+				complete[u] = speaks[u] && first[u] >= j0 && first[u] + r2[u].x <= tileEnd;
+				if ( complete[u] )
 				{
-					const uint32_t p = ex.y + ( gl - ex.w );
-					nextRefs[p] = r.tri;
-					nextRefNode[p] = c;
-					const uint32_t kdc = N.kind[c];
-					if ( kdc & K_SPLIT )
-						hist_add( N, c, kdc, r.tri, ext, nT, c0, sh, hist );
-				}
-				if ( r.right )
-				{
-					const uint32_t p = ex.y + T.cntL[r.node] + ( gr - ( ex.y - ex.w ) );
-					nextRefs[p] = r.tri;
-					nextRefNode[p] = c + 1u;
-					const uint32_t kdc = N.kind[c + 1u];
-					if ( kdc & K_SPLIT )
-						hist_add( N, c + 1u, kdc, r.tri, ext, nT, c0, sh, hist );
+					bx[u][0] = T.rec[(size_t) REC * node[u] + 4];
+					bx[u][1] = T.rec[(size_t) REC * node[u] + 5];
 				}
 			}
 		}
+		for ( int u = 0; u < RPT; ++u )
+		{
+			left[u] = right[u] = false;
+			if ( kind[u] & K_SPLIT )
+			{
+				const uint32_t c = 2u * ex[u].x;
+				const float sep = __uint_as_float( r1[u].y );
+				left[u] = pa[u] < sep;
+				right[u] = pb[u] > sep;
+				if ( left[u] && ( r2[u].y & K_SPLIT ) )
+					hist_add( c, r2[u].y, __uint_as_float( r3[u].x ), __uint_as_float( r3[u].y ), la[u], lb[u], c0, sh, hist );
+				if ( right[u] && ( r2[u].z & K_SPLIT ) )
+					hist_add( c + 1u, r2[u].z, __uint_as_float( r3[u].z ), __uint_as_float( r3[u].w ), ra[u], rb[u], c0, sh, hist );
+				if ( speaks[u] )
+					for ( uint32_t side = 0u; side < 2u; ++side )
+					{
+						const uint32_t cn = c + side, slot = cn - c0, kdc = side ? r2[u].z : r2[u].y;
+						if ( slot >= (uint32_t) HSLOTS || !( kdc & K_SPLIT ) )
+							continue;
+						SlotFacts f;
+						f.kind = kdc;
+						if ( complete[u] )
+						{
+							const uint4 q = bx[u][side];
+							f.kind = kdc | K_DONE;
+							f.box.c = __uint_as_float( q.x ); f.box.e = __uint_as_float( q.y );
+							f.box.eA = __uint_as_float( q.z ); f.box.eB = __uint_as_float( q.w );
+							f.box.mn = __uint_as_float( side ? r3[u].z : r3[u].x );
+							f.box.delta = __uint_as_float( side ? r3[u].w : r3[u].y );
+							N.kind[cn] = kdc | K_DONE;
+						}
+						facts[slot] = f;
+					}
+			}
+			mL[u] = __ballot( left[u] );
+			mR[u] = __ballot( right[u] );
+			if ( lane == 0u )
+			{
+				waveTot[( u * ( TB / 64 ) + w ) * 2] = (uint32_t) __popcll( mL[u] );
+				waveTot[( u * ( TB / 64 ) + w ) * 2 + 1] = (uint32_t) __popcll( mR[u] );
+			}
+		}
 		__syncthreads();
-		// (the first node of the tile goes on in the next one: its two children keep their counts in LDS)
-		const uint32_t keep = tileEnd < b1 && refNode[tileEnd] == node0 && ( kd0 & K_SPLIT ) ? 2u : 0u;
+		for ( int u = 0; u < RPT; ++u )
+		{
+			const uint32_t j = j0 + u * TB + threadIdx.x;
+			uint32_t gl = run[0], gr = run[1];
+			for ( uint32_t q = 0; q < TB / 64; ++q )
+			{
+				const uint32_t tl = waveTot[( u * ( TB / 64 ) + q ) * 2], tr = waveTot[( u * ( TB / 64 ) + q ) * 2 + 1];
+				if ( q < w ) { gl += tl; gr += tr; }
+				run[0] += tl;
+				run[1] += tr;
+			}
+			gl += (uint32_t) __popcll( mL[u] & below );
+			gr += (uint32_t) __popcll( mR[u] & below );
+			if ( j >= tileEnd )
+				continue;
+			if ( !( kind[u] & K_SPLIT ) )
+				leafPool[L.leafBase + ex[u].z + ( j - first[u] )] = tri[u];
+			else
+			{
+				const uint32_t c = 2u * ex[u].x;
+				if ( !left[u] && !right[u] )
+					atomicAdd( lostInPlane, 1u );             // (rare: a triangle flat in the split axis that lies in the plane)
+				if ( left[u] )
+				{
+					const uint32_t p = ex[u].y + ( gl - ex[u].w );
+					nextRefs[p] = tri[u];
+					nextRefNode[p] = c;
+				}
+				if ( right[u] )
+				{
+					const uint32_t p = ex[u].y + cl[u] + ( gr - ( ex[u].y - ex[u].w ) );
+					nextRefs[p] = tri[u];
+					nextRefNode[p] = c + 1u;
+				}
+			}
+		}
 		const uint32_t span = cEnd - c0;
-		finish_slots( N, c0, span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS, keep, sh, hist,
-			[&]( uint32_t cn ) { const uint32_t par = N.parent[cn], first = T.start[par]; return first >= j0 && first + T.count[par] <= tileEnd; } );
+		finish_slots( N, c0, span < (uint32_t) HSLOTS ? span : (uint32_t) HSLOTS, keep, sh, hist, facts );
 		__syncthreads();
 	}
 }
 
 // ---- finished tree: sizes, positions, output --------------------------------
-__global__ __launch_bounds__( TB ) void k_sizes( const uint2 *info, uint32_t first, uint32_t n, uint32_t *subNodes, uint32_t *subRefs, uint32_t *subDepth )
+// These kernels too take their counts from the state in device memory and are enqueued behind the levels without
+// the host knowing how the build went: fixed grids, grid-stride loops, nothing done for a level that does not exist.
+constexpr int G_FIN = 1024;
+
+struct SubTree             // per node, in level order
 {
-	const uint32_t k = blockIdx.x * TB + threadIdx.x;
-	if ( k >= n )
+	// x: the parent (level order), y: inner nodes before this one in its level, z: references in leaves before this one in
+	// its level, w: the level (written by k_children_count)
+	uint4 *walk;
+	uint32_t *pos, *refPos;             // pre-order number, first leaf reference in pre-order
+	uint32_t *longLeaves;               // the leaves k_emit leaves to k_emit_long
+};
+
+// Pre-order numbering, left child right behind its parent (:860-912), for all nodes at once.  Level order keeps the
+// children of neighbours next to each other, so "everything left of node x" is a prefix [0, r) of every level: the
+// nodes left of x's ancestors on the levels above, and below x's level the children of the prefix above - twice
+// the inner nodes in it.  x comes after all of those and after its ancestors, and after nothing else.  The same
+// walk over the leaf references left of x gives the place of a leaf's list.
+__global__ __launch_bounds__( TB ) void k_walk( const BuildState *st, SubTree sub )
+{
+	if ( st->overflow != OVF_NONE || st->nLevels == 0u )
 		return;
-	const uint32_t id = first + k;
-	const uint2 v = info[id];
-	if ( ( v.y & 3u ) == 3u )
+	const uint32_t n = st->nodesTotal, nL = st->nLevels;
+	for ( uint32_t id = blockIdx.x * TB + threadIdx.x; id < n; id += gridDim.x * TB )
 	{
-		subNodes[id] = 1u;
-		subRefs[id] = v.y >> 2;
-		subDepth[id] = 0u;
-		return;
+		const uint4 me = sub.walk[id];
+		const uint32_t d = me.w;
+		uint32_t p = d, rp = 0u;
+		uint4 w = me;
+		for ( uint32_t dd = d, cur = id; ; --dd )
+		{
+			p += cur - st->lv[dd].nodeBase;
+			rp += w.z;
+			if ( dd == 0u )
+				break;
+			cur = w.x;
+			w = sub.walk[cur];
+		}
+		uint32_t inner = me.y;
+		for ( uint32_t dd = d + 1u; dd < nL && inner != 0u; ++dd )
+		{
+			const uint32_t r = 2u * inner;
+			p += r;
+			if ( r < st->lv[dd].nodes )
+			{
+				const uint4 q = sub.walk[st->lv[dd].nodeBase + r];
+				rp += q.z;
+				inner = q.y;
+			}
+			else
+			{
+				rp += st->lv[dd + 1u].leafBase - st->lv[dd].leafBase;
+				inner = st->lv[dd + 1u].nodes / 2u;
+			}
+		}
+		sub.pos[id] = p;
+		sub.refPos[id] = rp;
 	}
-	const uint32_t l = v.y >> 2;
-	subNodes[id] = 1u + subNodes[l] + subNodes[l + 1];
-	subRefs[id] = subRefs[l] + subRefs[l + 1];
-	subDepth[id] = 1u + ( subDepth[l] > subDepth[l + 1] ? subDepth[l] : subDepth[l + 1] );
 }
 
-// pre-order numbering, left child right behind its parent (:860-912)
-__global__ __launch_bounds__( TB ) void k_positions( const uint2 *info, uint32_t first, uint32_t n, const uint32_t *subNodes, const uint32_t *subRefs,
-	uint32_t *pos, uint32_t *refPos )
+// Is there a finished tree, and does it fit the buffers the kernels below write to?  (They are allocated while the
+// levels run, from what the previous build came to; capNodes = 0: not yet.)
+__global__ void k_fit( BuildState *st, const GeomInfo *geom, uint32_t capNodes, uint32_t capRecs, uint32_t twoLists )
 {
-	const uint32_t k = blockIdx.x * TB + threadIdx.x;
-	if ( k >= n )
-		return;
-	const uint32_t id = first + k;
-	const uint2 v = info[id];
-	if ( ( v.y & 3u ) == 3u )
-		return;
-	const uint32_t l = v.y >> 2;
-	pos[l] = pos[id] + 1u;
-	pos[l + 1] = pos[id] + 1u + subNodes[l];
-	refPos[l] = refPos[id];
-	refPos[l + 1] = refPos[id] + subRefs[l];
+	const bool built = st->overflow == OVF_NONE && st->nLevels != 0u && geom->badIndex == 0u;
+	st->rootDepth = built ? st->nLevels - 1u : 0u;
+	st->nLong = 0u;
+	st->fits = built && st->nodesTotal <= capNodes && st->leafRefs <= capRecs && ( !twoLists || 2ull * st->leafRefs < ( 1ull << 30 ) ) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__( TB ) void k_emit( const uint2 *info, uint32_t n, const uint32_t *pos, const uint32_t *refPos, const uint32_t *leafPool,
-	rt_hip_kdnode *nodes, uint32_t *order )
+__global__ __launch_bounds__( TB ) void k_emit( BuildState *st, const uint2 *info, SubTree sub, const uint32_t *leafPool, rt_hip_kdnode *nodes,
+	uint32_t *order )
 {
-	const uint32_t id = blockIdx.x * TB + threadIdx.x;
-	if ( id >= n )
+	if ( !st->fits )
 		return;
-	const uint2 v = info[id];
-	rt_hip_kdnode o;
-	if ( ( v.y & 3u ) == 3u )
+	const uint32_t n = st->nodesTotal;
+	for ( uint32_t id = blockIdx.x * TB + threadIdx.x; id < n; id += gridDim.x * TB )
 	{
-		const uint32_t cnt = v.y >> 2, dst = refPos[id];
-		o.a = dst;
-		o.b = v.y;
-		for ( uint32_t k = 0; k < cnt; ++k )
+		const uint2 v = info[id];
+		rt_hip_kdnode o;
+		if ( ( v.y & 3u ) == 3u )
+		{
+			const uint32_t cnt = v.y >> 2, dst = sub.refPos[id];
+			o.a = dst;
+			o.b = v.y;
+			if ( cnt <= 32u )
+				for ( uint32_t k = 0; k < cnt; ++k )
+					order[dst + k] = leafPool[v.x + k];
+			else
+				sub.longLeaves[atomicAdd( &st->nLong, 1u )] = id;
+		}
+		else
+		{
+			o.a = v.x;
+			o.b = ( sub.pos[( v.y >> 2 ) + 1u] << 2 ) | ( v.y & 3u );
+		}
+		nodes[sub.pos[id]] = o;
+	}
+}
+
+// the leaf lists of more than 32 references (leaves at the depth limit), a wave per leaf
+__global__ __launch_bounds__( TB ) void k_emit_long( const BuildState *st, const uint2 *info, SubTree sub, const uint32_t *leafPool, uint32_t *order )
+{
+	if ( !st->fits )
+		return;
+	const uint32_t n = st->nLong, lane = threadIdx.x & 63u, waves = gridDim.x * ( TB / 64 );
+	for ( uint32_t q = blockIdx.x * ( TB / 64 ) + ( threadIdx.x >> 6 ); q < n; q += waves )
+	{
+		const uint32_t id = sub.longLeaves[q];
+		const uint2 v = info[id];
+		const uint32_t cnt = v.y >> 2, dst = sub.refPos[id];
+		for ( uint32_t k = lane; k < cnt; k += 64u )
 			order[dst + k] = leafPool[v.x + k];
 	}
-	else
-	{
-		o.a = v.x;
-		o.b = ( pos[( v.y >> 2 ) + 1u] << 2 ) | ( v.y & 3u );
-	}
-	nodes[pos[id]] = o;
 }
 
-__global__ __launch_bounds__( TB ) void k_records( const rt_vertex *verts, const rt_triangle *tris, const uint32_t *order, uint32_t nRecs, rt_hip_trirec *recs )
+__global__ __launch_bounds__( TB ) void k_records( const BuildState *st, const rt_vertex *verts, const rt_triangle *tris, const uint32_t *order,
+	rt_hip_trirec *recs )
 {
-	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i > nRecs )
+	if ( !st->fits )
 		return;
-	rt_hip_trirec r;
-	memset( &r, 0, sizeof( r ) );
-	if ( i < nRecs )              // entry nRecs is the zeroed spare record the look-ahead load may touch
+	const uint32_t nRecs = st->leafRefs;
+	for ( uint32_t i = blockIdx.x * TB + threadIdx.x; i <= nRecs; i += gridDim.x * TB )
 	{
-		const rt_triangle t = tris[order[i]];
-		const rt_vector3 p0 = verts[t.pV0].pos, p1 = verts[t.pV1].pos, p2 = verts[t.pV2].pos;
-		r.nv0x = -p0.x; r.nv0y = -p0.y; r.nv0z = -p0.z;
-		r.e1x = p1.x - p0.x; r.e1y = p1.y - p0.y; r.e1z = p1.z - p0.z;
-		r.e2x = p2.x - p0.x; r.e2y = p2.y - p0.y; r.e2z = p2.z - p0.z;
-		r.tri = order[i];
-		r.mat = (uint32_t) t.mat;
+		rt_hip_trirec r;
+		memset( &r, 0, sizeof( r ) );
+		if ( i < nRecs )              // entry nRecs is the zeroed spare record the look-ahead load may touch
+		{
+			const rt_triangle t = tris[order[i]];
+			const rt_vector3 p0 = verts[t.pV0].pos, p1 = verts[t.pV1].pos, p2 = verts[t.pV2].pos;
+			r.nv0x = -p0.x; r.nv0y = -p0.y; r.nv0z = -p0.z;
+			r.e1x = p1.x - p0.x; r.e1y = p1.y - p0.y; r.e1z = p1.z - p0.z;
+			r.e2x = p2.x - p0.x; r.e2y = p2.y - p0.y; r.e2z = p2.z - p0.z;
+			r.tri = order[i];
+			r.mat = (uint32_t) t.mat;
+		}
+		recs[i] = r;
 	}
-	recs[i] = r;
 }
 
-__global__ __launch_bounds__( TB ) void k_shade_records( const rt_vertex *verts, const rt_triangle *tris, uint32_t nT, rt_hip_trishade *shade )
+// (needs no tree, only indices that have been checked: k_extents ran before)
+__global__ __launch_bounds__( TB ) void k_shade_records( const GeomInfo *geom, const rt_vertex *verts, const rt_triangle *tris, uint32_t nT,
+	rt_hip_trishade *shade )
 {
 	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i >= nT )
+	if ( i >= nT || geom->badIndex != 0u )
 		return;
 	const rt_triangle t = tris[i];
 	const rt_vector3 n0 = verts[t.pV0].norm, n1 = verts[t.pV1].norm, n2 = verts[t.pV2].norm;
@@ -1025,10 +1308,10 @@ __device__ bool tri_touches_cell( const double q[3][3], const float lo[3], const
 // the records of the triangles that touch the cell to the front of the leaf's range, in order, and
 // lowers the leaf's count.  The records behind them stay where they are, unused.  Nothing is done
 // when the build dropped a reference (see rt_kdtree.h: such a tree keeps the reference's lists).
-__global__ __launch_bounds__( TB ) void k_prune_leaves( rt_hip_kdnode *nodes, uint32_t nNodes, rt_hip_trirec *recs, const GeomInfo *geom, float margin )
+__global__ __launch_bounds__( TB ) void k_prune_leaves( const BuildState *st, rt_hip_kdnode *nodes, rt_hip_trirec *recs, const GeomInfo *geom, float margin )
 {
 	const uint32_t leaf = blockIdx.x * TB + threadIdx.x;
-	if ( leaf >= nNodes || geom->lostInPlane != 0u )
+	if ( !st->fits || leaf >= st->nodesTotal || geom->lostInPlane != 0u )
 		return;
 	const rt_hip_kdnode me = nodes[leaf];
 	if ( ( me.b & 3u ) != 3u || ( me.b >> 2 ) == 0u )
@@ -1080,11 +1363,12 @@ __global__ __launch_bounds__( TB ) void k_prune_leaves( rt_hip_kdnode *nodes, ui
 }
 
 // where every leaf's complete list lies once a copy of the record array has been put behind it (`shift` records on)
-__global__ __launch_bounds__( TB ) void k_leaf_full( const rt_hip_kdnode *nodes, uint32_t nNodes, uint32_t shift, rt_hip_leaf_full *full )
+__global__ __launch_bounds__( TB ) void k_leaf_full( const BuildState *st, const rt_hip_kdnode *nodes, rt_hip_leaf_full *full )
 {
 	const uint32_t i = blockIdx.x * TB + threadIdx.x;
-	if ( i >= nNodes )
+	if ( !st->fits || i >= st->nodesTotal )
 		return;
+	const uint32_t shift = st->leafRefs;
 	const rt_hip_kdnode n = nodes[i];
 	rt_hip_leaf_full f = { 0u, 0u };
 	if ( ( n.b & 3u ) == 3u )
@@ -1095,12 +1379,26 @@ __global__ __launch_bounds__( TB ) void k_leaf_full( const rt_hip_kdnode *nodes,
 	full[i] = f;
 }
 
+// the complete record array once more behind itself (16 bytes per thread and step), and the spare record at the very end
+__global__ __launch_bounds__( TB ) void k_copy_full( const BuildState *st, rt_hip_trirec *recs )
+{
+	static_assert( sizeof( rt_hip_trirec ) % sizeof( uint4 ) == 0, "records are copied in 16-byte pieces" );
+	if ( !st->fits )
+		return;
+	const size_t per = sizeof( rt_hip_trirec ) / sizeof( uint4 ), n = (size_t) st->leafRefs * per;
+	const uint4 *from = (const uint4 *) recs;
+	uint4 *to = (uint4 *) ( recs + st->leafRefs );
+	for ( size_t i = (size_t) blockIdx.x * TB + threadIdx.x; i < n + per; i += (size_t) gridDim.x * TB )
+		to[i] = i < n ? from[i] : make_uint4( 0u, 0u, 0u, 0u );
+}
+
 inline unsigned grid_of( size_t n ) { return (unsigned) ( ( n + TB - 1 ) / TB ); }
 
 struct Scratch
 {
 	DVec verts, tris, ext, refsA, refsB, tabA, tabB, hist, sums, info, leafPool, sub, order, geom, state;
 	Caps caps = { 0u, 0u, 0u, 0u };
+	uint32_t lastNT = 0xffffffffu, lastNodes = 0, lastRecs = 0;      // what the previous build of this thread came to
 	bool histClean = false;      // every entry of `hist` is zero (each level leaves it so; a build that failed half-way may not)
 	void *pinned = nullptr;      // BuildState + GeomInfo as the host reads them
 	void release()
@@ -1111,6 +1409,7 @@ struct Scratch
 		pinned = nullptr;
 		caps = Caps{ 0u, 0u, 0u, 0u };
 		histClean = false;
+		lastNT = 0xffffffffu;
 	}
 };
 thread_local Scratch g_scratch;
@@ -1121,7 +1420,7 @@ int node_tab( DVec &buf, size_t n, hipStream_t s, NodeTab &t )
 {
 	if ( int rc = buf.reserve( n * NODE_TAB_WORDS * sizeof( uint32_t ), s ) ) return rc;
 	uint32_t *p = buf.as<uint32_t>();
-	t.excl = (uint4 *) p; p += 4 * n;          // first: 16-byte aligned
+	t.rec = (uint4 *) p; p += 4 * REC * n;          // first: 16-byte aligned
 	t.box = (float *) p; p += 6 * n;
 	t.start = p; p += n;
 	t.count = p; p += n;
@@ -1179,10 +1478,64 @@ extern "C" int rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle
 	return rt_kdtree_build_device_ex( verts, tris, vertexCount, trianglesCount, &o, hipStream, out );
 }
 
+// the buffers the finished tree is written to (owned by the caller once the build has succeeded)
+struct ResultBufs
+{
+	uint32_t capNodes = 0, capRecs = 0;      // what out->nodes / out->recs (one list) / out->leafFull have room for
+	bool two = false;                        // the record array has room for the lists twice, out->leafFull exists
+};
+
+static void free_result( rt_kdtree_device *out, ResultBufs &fin )
+{
+	if ( out->nodes ) (void) hipFree( out->nodes );
+	if ( out->recs ) (void) hipFree( out->recs );
+	if ( out->leafFull ) (void) hipFree( out->leafFull );
+	out->nodes = out->recs = out->leafFull = nullptr;
+	fin = ResultBufs();
+}
+
+static int alloc_result( rt_kdtree_device *out, size_t nodes, size_t recs, bool two, ResultBufs &fin )
+{
+	hipError_t ea = hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * ( nodes ? nodes : 1 ) );
+	if ( ea == hipSuccess ) ea = hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( recs * ( two ? 2 : 1 ) + 1 ) );
+	if ( ea == hipSuccess && two ) ea = hipMalloc( &out->leafFull, sizeof( rt_hip_leaf_full ) * ( nodes ? nodes : 1 ) );
+	if ( ea != hipSuccess )
+	{
+		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );
+		(void) hipGetLastError();
+		free_result( out, fin );
+		return 10;
+	}
+	fin.capNodes = (uint32_t) nodes;
+	fin.capRecs = (uint32_t) recs;
+	fin.two = two;
+	return 0;
+}
+
+// nodes, leaf records (and the pruned lists in front of the complete ones) into the result's buffers - if the tree
+// the state describes fits them (k_fit; not at all while there are no buffers)
+static int enqueue_result( Scratch &S, const SubTree &sub, BuildState *dState, GeomInfo *dGeom, const ResultBufs &fin, float pruneLeaves, hipStream_t s,
+	rt_kdtree_device *out );
+
+static int build_device( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount, uint64_t trianglesCount,
+	const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out );
+
 extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out )
 {
 	g_gpu_build_err[0] = 0;
+	if ( !out )
+		return 1;
+	memset( out, 0, sizeof( *out ) );
+	const int rc = build_device( verts, tris, vertexCount, trianglesCount, opts, hipStream, out );
+	if ( rc != 0 )
+		rt_kdtree_device_release( out );          // (whatever had been allocated for the result by then)
+	return rc;
+}
+
+static int build_device( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount, uint64_t trianglesCount,
+	const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out )
+{
 	if ( !opts )
 		return 1;
 	if ( opts->sahStop > 0.0f || opts->allAxes )
@@ -1192,7 +1545,6 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		return 1;
 	if ( trianglesCount >= ( 1ull << 30 ) || maxDepth < 0 || maxDepth > RT_HIP_MAX_TREE_DEPTH || maxPrims < 1 )
 		return 2;
-	memset( out, 0, sizeof( *out ) );
 	hipStream_t s = (hipStream_t) hipStream;
 	const uint32_t nT = (uint32_t) trianglesCount;
 
@@ -1206,7 +1558,7 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		g_scratch.release();
 		g_scratchDev = dev;
 	}
-	const bool TT = getenv( "RT_KD_TIMING" ) != nullptr;
+	const bool TT = getenv( "RT_KD_TIMING" ) != nullptr;      // (development aid: host time at which each phase was reached, to stderr)
 	auto t0_ = std::chrono::steady_clock::now();
 	auto stamp = [&]( const char *what ) { if ( TT ) { fprintf( stderr, "  %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>( std::chrono::steady_clock::now() - t0_ ).count() ); } };
 	Scratch &S = g_scratch;
@@ -1257,6 +1609,8 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 		if ( S.caps.nodesTotal < want.nodesTotal ) S.caps.nodesTotal = want.nodesTotal;
 		if ( S.caps.leaf < want.leaf ) S.caps.leaf = want.leaf;
 	}
+	const bool wantTwo = opts->pruneLeaves > 0.0f;
+	ResultBufs fin;
 	for ( int attempt = 0; ; ++attempt )
 	{
 		const Caps caps = S.caps;
@@ -1274,6 +1628,12 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 				GCHK( hipMemsetAsync( S.hist.p, 0, S.hist.cap, s ) );
 			S.histClean = false;
 		}
+		if ( int rc = S.sub.reserve( ( sizeof( uint4 ) + 3 * sizeof( uint32_t ) ) * (size_t) caps.nodesTotal, s ) ) return rc;
+		SubTree sub;
+		sub.walk = S.sub.as<uint4>();
+		sub.pos = (uint32_t *) ( sub.walk + caps.nodesTotal );
+		sub.refPos = sub.pos + caps.nodesTotal;
+		sub.longLeaves = sub.refPos + caps.nodesTotal;
 		uint32_t *refBuf[2] = { S.refsA.as<uint32_t>(), S.refsB.as<uint32_t>() };
 		if ( nT ) LAUNCH( k_iota, dim3( grid_of( nT ) ), dim3( TB ), 0, s, refBuf[0], refBuf[0] + caps.refs, nT );
 		GCHK( hipMemsetAsync( &dGeom->lostInPlane, 0, sizeof( uint32_t ), s ) );
@@ -1285,25 +1645,77 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 			const uint32_t *refs = refBuf[depth & 1], *refNode = refs + caps.refs;
 			uint32_t *nRefs = refBuf[( depth + 1 ) & 1], *nRefNode = nRefs + caps.refs;
 			if ( nT && depth == 0 )
-				LAUNCH( k_hist, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), refs, refNode, S.ext.as<float>(), nT );
+				LAUNCH( k_hist, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), refs, refNode, Ext{ S.ext.as<float>(), nT } );
 			LAUNCH( k_split, dim3( G_NODE * SPLIT_FINER ), dim3( TB ), 0, s, dState, depth, cur, S.hist.as<uint32_t>(), nodeSums );
-			LAUNCH( k_children_count, dim3( G_NODE + ( nT ? G_REF : 0 ) ), dim3( TB ), 0, s, dState, depth, cur, next, nodeSums, S.info.as<uint2>(), caps,
-				maxDepth, maxPrims, refs, refNode, S.ext.as<float>(), nT, refSums );
+			LAUNCH( k_children_count, dim3( G_NODE + ( nT ? G_REF : 0 ) ), dim3( TB ), 0, s, dState, depth, cur, next, nodeSums, S.info.as<uint2>(), sub.walk, caps,
+				maxDepth, maxPrims, refs, refNode, Ext{ S.ext.as<float>(), nT }, refSums );
 			if ( nT )
-				LAUNCH( k_scatter, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, next, refs, refNode, S.ext.as<float>(), nT, refSums,
+				LAUNCH( k_scatter, dim3( G_REF ), dim3( TB ), 0, s, dState, depth, cur, next, refs, refNode, Ext{ S.ext.as<float>(), nT }, refSums,
 					nRefs, nRefNode, S.leafPool.as<uint32_t>(), S.hist.as<uint32_t>(), &dGeom->lostInPlane );
 		}
+		// pre-order positions
+		LAUNCH( k_walk, dim3( G_FIN ), dim3( TB ), 0, s, dState, sub );
 		stamp( "levels enqueued" );
+
+		// While all that runs: the result's buffers, sized by what the previous build of as many triangles came to
+		// (a frame loop rebuilds about the same tree every frame; allocating 0.4 GB takes 0.3 ms, a twelfth of a build).
+		if ( !out->shade )
+		{
+			hipError_t ea = hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
+			if ( ea != hipSuccess )
+			{
+				snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );
+				return 10;
+			}
+			if ( nT )
+				LAUNCH( k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, dGeom, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
+					(rt_hip_trishade *) out->shade );
+			if ( S.lastNT == nT )
+				if ( int rc = alloc_result( out, (size_t) S.lastNodes + S.lastNodes / 8 + 1024, (size_t) S.lastRecs + S.lastRecs / 8 + 1024, wantTwo, fin ) )
+				{
+					(void) rc;                       // (the exact sizes will be tried once they are known)
+					g_gpu_build_err[0] = 0;
+				}
+		}
+		// ... and the tree into them, if it turns out to fit
+		if ( int rc = enqueue_result( S, sub, dState, dGeom, fin, opts->pruneLeaves, s, out ) ) return rc;
 		GCHK( hipMemcpyAsync( hState, dState, sizeof( BuildState ), hipMemcpyDeviceToHost, s ) );
 		GCHK( hipMemcpyAsync( hGeom, dGeom, sizeof( GeomInfo ), hipMemcpyDeviceToHost, s ) );
-		GCHK( hipGetLastError() );
 		GCHK( hipStreamSynchronize( s ) );
 		stamp( "levels done" );
 		S.histClean = true;
 		if ( hGeom->badIndex )
 			return 3;
 		if ( hState->overflow == OVF_NONE )
+		{
+			if ( hState->nLevels < 1 || (int) hState->nLevels > maxDepth + 1 || hState->nodesTotal == 0 )
+			{
+				snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "kd build left an inconsistent state (%u levels, %u nodes)", hState->nLevels,
+					hState->nodesTotal );
+				return 10;
+			}
+			if ( wantTwo && 2ull * hState->leafRefs >= ( 1ull << 30 ) )
+			{
+				snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "pruned and complete leaf lists together exceed the 30-bit record index" );
+				return 4;
+			}
+			if ( !hState->fits )
+			{
+				// the first build of this size, or one that outgrew the guess: now that the sizes are known
+				free_result( out, fin );
+				if ( int rc = alloc_result( out, hState->nodesTotal, hState->leafRefs, wantTwo, fin ) ) return rc;
+				stamp( "outputs allocated" );
+				if ( int rc = enqueue_result( S, sub, dState, dGeom, fin, opts->pruneLeaves, s, out ) ) return rc;
+				GCHK( hipMemcpyAsync( hState, dState, sizeof( BuildState ), hipMemcpyDeviceToHost, s ) );
+				GCHK( hipStreamSynchronize( s ) );
+				if ( !hState->fits )
+				{
+					snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "kd build: the tree does not fit the buffers allocated for it" );
+					return 10;
+				}
+			}
 			break;
+		}
 		uint32_t *grow = hState->overflow == OVF_REFS ? &S.caps.refs : hState->overflow == OVF_LEVEL_NODES ? &S.caps.levelNodes :
 			hState->overflow == OVF_NODES ? &S.caps.nodesTotal : hState->overflow == OVF_LEAF ? &S.caps.leaf : nullptr;
 		if ( !grow || *grow >= ( 1u << 30 ) || attempt >= 64 )
@@ -1315,86 +1727,45 @@ extern "C" int rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_trian
 	out->maxMaterial = hGeom->maxMat;
 	out->bbox.center.x = hGeom->box[0]; out->bbox.center.y = hGeom->box[1]; out->bbox.center.z = hGeom->box[2];
 	out->bbox.extents.x = hGeom->box[3]; out->bbox.extents.y = hGeom->box[4]; out->bbox.extents.z = hGeom->box[5];
-	const int nLevels = (int) hState->nLevels;
-	const uint64_t nodesTotal = hState->nodesTotal, leafRefs = hState->leafRefs;
-	if ( nLevels < 1 || nLevels > maxDepth + 1 || nodesTotal == 0 )
+	const uint32_t nNodes = hState->nodesTotal, nRecs = hState->leafRefs, rootDepth = hState->rootDepth;
+	const bool twoLists = wantTwo && nRecs != 0u;
+	if ( out->leafFull && !twoLists )
 	{
-		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "kd build left an inconsistent state (%d levels, %llu nodes)", nLevels,
-			(unsigned long long) nodesTotal );
-		return 10;
-	}
-
-	// sizes bottom-up, positions top-down
-	const uint32_t nNodes = (uint32_t) nodesTotal;
-	if ( int rc = S.sub.reserve( 5 * sizeof( uint32_t ) * (size_t) nNodes, s ) ) return rc;
-	uint32_t *subNodes = S.sub.as<uint32_t>(), *subRefs = subNodes + nNodes, *subDepth = subRefs + nNodes, *pos = subDepth + nNodes, *refPos = pos + nNodes;
-	const uint2 *info = S.info.as<uint2>();
-	for ( int d = nLevels - 1; d >= 0; --d )
-		LAUNCH( k_sizes, dim3( grid_of( hState->lv[d].nodes ) ), dim3( TB ), 0, s, info, hState->lv[d].nodeBase, hState->lv[d].nodes,
-			subNodes, subRefs, subDepth );
-	GCHK( hipMemsetAsync( pos, 0, sizeof( uint32_t ), s ) );
-	GCHK( hipMemsetAsync( refPos, 0, sizeof( uint32_t ), s ) );
-	for ( int d = 0; d < nLevels; ++d )
-		LAUNCH( k_positions, dim3( grid_of( hState->lv[d].nodes ) ), dim3( TB ), 0, s, info, hState->lv[d].nodeBase, hState->lv[d].nodes,
-			subNodes, subRefs, pos, refPos );
-	uint32_t rootDepth = 0;
-	GCHK( hipMemcpyAsync( &rootDepth, subDepth, sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
-
-	// output buffers (owned by the caller from here on)
-	const uint32_t nRecs = (uint32_t) leafRefs;
-	// pruned lists: the complete ones are kept behind them (read by rays parallel to an axis, see rt_kdtree.h)
-	const bool twoLists = opts->pruneLeaves > 0.0f && nRecs != 0u;
-	if ( twoLists && 2ull * nRecs >= ( 1ull << 30 ) )
-	{
-		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "pruned and complete leaf lists together exceed the 30-bit record index" );
-		return 4;
-	}
-	const size_t nAll = (size_t) nRecs * ( twoLists ? 2 : 1 );
-	{
-		hipError_t ea = hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * (size_t) nNodes );
-		if ( ea == hipSuccess ) ea = hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( nAll + 1 ) );
-		if ( ea == hipSuccess ) ea = hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
-		if ( ea == hipSuccess && twoLists ) ea = hipMalloc( &out->leafFull, sizeof( rt_hip_leaf_full ) * (size_t) nNodes );
-		if ( ea != hipSuccess )
-		{
-			snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );
-			rt_kdtree_device_release( out );
-			return 10;
-		}
-	}
-	stamp( "outputs allocated" );
-	if ( int rc = S.order.reserve( sizeof( uint32_t ) * ( (size_t) nRecs + 1 ), s ) ) { rt_kdtree_device_release( out ); return rc; }
-	LAUNCH_OR( rt_kdtree_device_release( out ), k_emit, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, info, nNodes, pos, refPos, S.leafPool.as<uint32_t>(),
-		(rt_hip_kdnode *) out->nodes, S.order.as<uint32_t>() );
-	LAUNCH_OR( rt_kdtree_device_release( out ), k_records, dim3( grid_of( (size_t) nRecs + 1 ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(),
-		S.order.as<uint32_t>(), nRecs, (rt_hip_trirec *) out->recs );
-	if ( nT )
-		LAUNCH_OR( rt_kdtree_device_release( out ), k_shade_records, dim3( grid_of( nT ) ), dim3( TB ), 0, s, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), nT,
-			(rt_hip_trishade *) out->shade );
-	if ( twoLists )
-	{
-		rt_hip_trirec *recs = (rt_hip_trirec *) out->recs;
-		LAUNCH_OR( rt_kdtree_device_release( out ), k_leaf_full, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (const rt_hip_kdnode *) out->nodes, nNodes, nRecs,
-			(rt_hip_leaf_full *) out->leafFull );
-		GCHK( hipMemcpyAsync( recs + nRecs, recs, sizeof( rt_hip_trirec ) * (size_t) nRecs, hipMemcpyDeviceToDevice, s ) );
-		GCHK( hipMemsetAsync( recs + 2 * (size_t) nRecs, 0, sizeof( rt_hip_trirec ), s ) );       // the spare record at the very end
-		LAUNCH_OR( rt_kdtree_device_release( out ), k_prune_leaves, dim3( grid_of( nNodes ) ), dim3( TB ), 0, s, (rt_hip_kdnode *) out->nodes, nNodes,
-			recs, dGeom, opts->pruneLeaves );
-	}
-	hipError_t e = hipGetLastError();
-	if ( e == hipSuccess ) e = hipStreamSynchronize( s );
-	if ( e != hipSuccess )
-	{
-		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "kd build kernels failed: %s", hipGetErrorString( e ) );
-		rt_kdtree_device_release( out );
-		return 10;
+		(void) hipFree( out->leafFull );
+		out->leafFull = nullptr;
 	}
 	stamp( "done" );
+	S.lastNT = nT;
+	S.lastNodes = nNodes;
+	S.lastRecs = nRecs;
 	out->nNodes = nNodes;
 	out->nRecs = nRecs;
 	out->nRecsFull = twoLists ? nRecs : 0;
 	out->nTris = nT;
 	out->depth = (int) rootDepth;
+	return 0;
+}
+
+static int enqueue_result( Scratch &S, const SubTree &sub, BuildState *dState, GeomInfo *dGeom, const ResultBufs &fin, float pruneLeaves, hipStream_t s,
+	rt_kdtree_device *out )
+{
+	LAUNCH( k_fit, dim3( 1 ), dim3( 1 ), 0, s, dState, dGeom, fin.capNodes, fin.capRecs, fin.two ? 1u : 0u );
+	if ( !out->nodes )
+		return 0;
+	const uint2 *info = S.info.as<uint2>();
+	rt_hip_kdnode *nodes = (rt_hip_kdnode *) out->nodes;
+	rt_hip_trirec *recs = (rt_hip_trirec *) out->recs;
+	if ( int rc = S.order.reserve( sizeof( uint32_t ) * ( (size_t) fin.capRecs + 1 ), s ) ) return rc;
+	LAUNCH( k_emit, dim3( G_FIN ), dim3( TB ), 0, s, dState, info, sub, S.leafPool.as<uint32_t>(), nodes, S.order.as<uint32_t>() );
+	LAUNCH( k_emit_long, dim3( G_FIN ), dim3( TB ), 0, s, dState, info, sub, S.leafPool.as<uint32_t>(), S.order.as<uint32_t>() );
+	LAUNCH( k_records, dim3( 4 * G_FIN ), dim3( TB ), 0, s, dState, S.verts.as<rt_vertex>(), S.tris.as<rt_triangle>(), S.order.as<uint32_t>(), recs );
+	if ( fin.two )
+	{
+		// pruned lists: the complete ones are kept behind them (read by rays parallel to an axis, see rt_kdtree.h)
+		LAUNCH( k_leaf_full, dim3( grid_of( fin.capNodes ) ), dim3( TB ), 0, s, dState, nodes, (rt_hip_leaf_full *) out->leafFull );
+		LAUNCH( k_copy_full, dim3( 4 * G_FIN ), dim3( TB ), 0, s, dState, recs );
+		LAUNCH( k_prune_leaves, dim3( grid_of( fin.capNodes ) ), dim3( TB ), 0, s, dState, nodes, recs, dGeom, pruneLeaves );
+	}
 	return 0;
 }
 
