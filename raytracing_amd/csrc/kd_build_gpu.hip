@@ -3,21 +3,29 @@
 // produced level by level in HBM and emitted directly in the layout the
 // traversal kernels read, so a rebuilt tree never crosses PCIe.
 //
-// One level = the set of nodes of one depth.  Per level:
-//   k_decide    node  : leaf (count <= maxPrims or depth == maxDepth) or split axis + candidate planes
-//   k_hist      ref   : histogram of every triangle extent against the 32 planes of its node
-//   k_split     node  : counts left / right of every plane, SAH cost, lowest-index minimum
-//   scan        node  : child node numbers, child reference ranges, leaf pool ranges (one hipCUB scan over triples)
-//   k_children  node  : child boxes, next level's node table, this node's record of the tree
-//   scan of flags + k_scatter   ref : STABLE partition of the triangle references
-//                       (a reference goes left if min < sep, right if max > sep, possibly both)
-// then, over the finished tree: sub-tree sizes bottom-up, pre-order positions
-// top-down (left child = own index + 1), nodes + leaf records + shading records.
+// One level = the set of nodes of one depth; a node is decided (leaf, or split
+// axis + 32 candidate planes) when its parent creates it.  Per level, three launches:
+//   k_split           node : SAH cost of the 32 planes from the node's histogram, lowest-index minimum - for the
+//                            nodes that did not get their split from the kernel that counted them; block sums
+//   k_children_count  node : child numbers and reference ranges (scan over the level), child boxes, leaf / inner
+//                            decision for the children, the level's records of the tree, the next level's state
+//                     ref  : (other blocks of the same launch) left / right counts per block
+//   k_scatter         ref  : STABLE partition of the triangle references (a reference goes left if min < sep,
+//                            right if max > sep, possibly both); on the way the histogram of every reference
+//                            against the planes of the child it goes to, and the split of every child whose
+//                            parent's references lie inside one tile, from histograms in LDS
+// (k_hist counts the root's references).  Then, over the finished tree: pre-order positions (left child =
+// own index + 1) for all nodes at once, nodes + leaf records + shading records.
+//
+// The level loop runs without the host: level counts live in a state block in device memory, launches have
+// fixed grids, work buffers are sized from the triangle count (a level that does not fit says so, the buffer is
+// doubled and the levels run again).  The result's buffers are allocated while the levels run, sized by the
+// previous build of as many triangles, and filled before the one synchronisation of the build; the first build
+// of a size allocates them after it and synchronises once more.
 //
 // fp32 expressions are the host builder's, operand for operand, and the file
 // is compiled with -ffp-contract=off: the result is the host tree bit for bit
-// (tests/test_kdtree_gpu.py).  The host drives the level loop and reads three
-// totals per level to size the next one.
+// (tests/test_kdtree_gpu.py).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -39,10 +47,9 @@ constexpr int TB = 256;
 thread_local char g_gpu_build_err[512] = "";
 
 // a launch that is refused (grid, block or LDS size) says so at once, by name
-#define LAUNCH_OR( cleanup, kernel, ... ) do { hipLaunchKernelGGL( kernel, __VA_ARGS__ ); hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { \
+#define LAUNCH( kernel, ... ) do { hipLaunchKernelGGL( kernel, __VA_ARGS__ ); hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { \
 	snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "launch of %s failed: %s (%s:%d)", #kernel, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
-	cleanup; return 10; } } while ( 0 )
-#define LAUNCH( ... ) LAUNCH_OR( (void) 0, __VA_ARGS__ )
+	return 10; } } while ( 0 )
 
 // device buffer that grows (contents are NOT kept unless keep > 0)
 struct DVec
@@ -674,30 +681,6 @@ __global__ __launch_bounds__( TB ) void k_split( const BuildState *st, int depth
 		blockSums[blockIdx.x] = make_uint4( acc[0], acc[1], acc[2], acc[3] );
 }
 
-// does reference j go to the left / right child of its node (min < sep / max > sep, :971-1029)
-struct RefSide
-{
-	uint32_t node, kind, tri;
-	bool left, right;
-};
-
-__device__ inline RefSide ref_side( const NodeTab &T, const uint32_t *refs, const uint32_t *refNode, const Ext &ext, uint32_t j )
-{
-	RefSide r;
-	r.node = refNode[j];
-	r.kind = T.kind[r.node];
-	r.tri = refs[j];
-	r.left = r.right = false;
-	if ( r.kind & K_SPLIT )
-	{
-		const uint32_t ax = ( r.kind >> 1 ) & 3u;
-		const float sep = T.sep[r.node];
-		r.left = ext.lo( ax, r.tri ) < sep;
-		r.right = ext.hi( ax, r.tri ) > sep;
-	}
-	return r;
-}
-
 // what k_children_count reads of a node
 struct NodeFacts
 {
@@ -725,8 +708,8 @@ __device__ __forceinline__ NodeFacts node_facts( const NodeTab &T, uint32_t i )
 // then inside the block), write the child boxes - slab split at sep (:1034-1073) -, decide leaf / inner node for
 // them, write this level's records of the tree in level order, and the next level's state.  Every block works out the
 // level's totals for itself, so all of them agree whether the next level fits the work buffers.
-// Blocks [G_NODE, G_NODE + G_REF): references going left / right in every block's share of the level (the first
-// step of the partition's scan).
+// Blocks [G_NODE, G_NODE + G_REF): references going left / right (min < sep / max > sep, :971-1029) in every block's
+// share of the level (the first step of the partition's scan).
 __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int depth, NodeTab T, NodeTab N, const uint4 *blockSums, uint2 *info, uint4 *walk,
 	Caps caps, int maxDepth, int maxPrims, const uint32_t *refs, const uint32_t *refNode, Ext ext, uint2 *refSums )
 {
@@ -743,11 +726,38 @@ __global__ __launch_bounds__( TB ) void k_children_count( BuildState *st, int de
 		uint32_t b0, b1;
 		ref_share( L, G_REF, blockIdx.x - G_NODE, TILE, b0, b1 );
 		uint32_t acc[2] = { 0u, 0u };
-		for ( uint32_t j = b0 + threadIdx.x; j < b1; j += TB )
+		// (four references per thread under way at once: the three rounds of loads of one are all there is to wait for)
+		for ( uint32_t j = b0 + threadIdx.x; j < b1; j += 4 * TB )
 		{
-			const RefSide r = ref_side( T, refs, refNode, ext, j );
-			acc[0] += r.left ? 1u : 0u;
-			acc[1] += r.right ? 1u : 0u;
+			uint32_t node[4], tri[4], kd[4];
+			float sep[4], lo[4], hi[4];
+#pragma unroll
+			for ( int u = 0; u < 4; ++u )
+			{
+				const uint32_t ju = j + u * TB < b1 ? j + u * TB : j;      // (past the end: the first one again, not counted)
+				node[u] = refNode[ju];
+				tri[u] = refs[ju];
+			}
+#pragma unroll
+			for ( int u = 0; u < 4; ++u )
+			{
+				kd[u] = T.kind[node[u]];
+				sep[u] = T.sep[node[u]];
+			}
+#pragma unroll
+			for ( int u = 0; u < 4; ++u )
+			{
+				const uint32_t ax = ( kd[u] >> 1 ) & 3u;
+				lo[u] = ext.lo( ax, tri[u] );
+				hi[u] = ext.hi( ax, tri[u] );
+			}
+#pragma unroll
+			for ( int u = 0; u < 4; ++u )
+				if ( ( kd[u] & K_SPLIT ) && j + u * TB < b1 )
+				{
+					acc[0] += lo[u] < sep[u] ? 1u : 0u;
+					acc[1] += hi[u] > sep[u] ? 1u : 0u;
+				}
 		}
 		block_sum( acc, red );
 		if ( threadIdx.x == 0 )
