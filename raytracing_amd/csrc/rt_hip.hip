@@ -193,6 +193,8 @@ struct Counters
 	unsigned long long tExpand[RT_MAX_SLOTS], tScan[RT_MAX_SLOTS], tCoop[RT_MAX_SLOTS], tChunk[RT_MAX_SLOTS];
 	unsigned long long tDescend[RT_MAX_SLOTS], tLeaf[RT_MAX_SLOTS], tFinish[RT_MAX_SLOTS], tSetup[RT_MAX_SLOTS];
 	uint32_t maxLock[RT_MAX_SLOTS], maxCoop[RT_MAX_SLOTS], maxIters[RT_MAX_SLOTS];
+	// direction octants of the rays of a chunk: distinct ones, rays in the most frequent one, rays
+	unsigned long long octDistinct[RT_MAX_SLOTS], octMajor[RT_MAX_SLOTS], octRays[RT_MAX_SLOTS];
 #endif
 	unsigned long long nodeVisits, triTests, spillPushes, maxStack;   // STATS builds only
 	unsigned long long nodeVisitsShadow, triTestsShadow;              // share of the shadow queries
@@ -1744,6 +1746,23 @@ __global__ __launch_bounds__( RT_BLOCK, WAVES ) void k_closest( DevScene S, Work
 		}
 #ifdef RT_PROFILE_CHUNKS
 		Prof pf = { 0u, 0u, 0u, 0ull, 0ull, 0ull, 0ull, 0ull };
+		{
+			const uint32_t oct = ( rh.ray.dest.x < 0.0f ? 1u : 0u ) | ( rh.ray.dest.y < 0.0f ? 2u : 0u ) | ( rh.ray.dest.z < 0.0f ? 4u : 0u );
+			uint32_t distinct = 0u, major = 0u;
+			for ( uint32_t o = 0u; o < 8u; ++o )
+			{
+				const uint32_t n = (uint32_t) __popcll( __ballot( valid && oct == o ) );
+				distinct += n ? 1u : 0u;
+				major = n > major ? n : major;
+			}
+			const unsigned long long nValid = (unsigned long long) __popcll( __ballot( valid ) );
+			if ( lane_id() == 0u )
+			{
+				atomicAdd( &W.ctr->octDistinct[slot], (unsigned long long) distinct );
+				atomicAdd( &W.ctr->octMajor[slot], (unsigned long long) major );
+				atomicAdd( &W.ctr->octRays[slot], nValid );
+			}
+		}
 		const unsigned long long c0 = wall_clock64();
 #endif
 		nearest_wave<STATS>( S, rh.ray, tri_ray( rh.ray.src, rh.ray.dest ), st, live, t, h, tl, W.coopLive & 0xffu, W.coopCap, shift < 6u && ( W.coopLive >> 31 ) PROF_PASS );
@@ -3175,6 +3194,7 @@ int rt_hip_get_stats( rt_hip_ctx *c, rt_hip_stats *out )
 		const double n = h.chunksSeen[k] ? (double) h.chunksSeen[k] : 1.0;
 		fprintf( stderr, " [us per chunk: total %.1f, cooperative %.1f of which expand %.1f scan %.1f]", h.tChunk[k] / n / 100.0, h.tCoop[k] / n / 100.0, h.tExpand[k] / n / 100.0, h.tScan[k] / n / 100.0 );
 		fprintf( stderr, " [lane-per-ray: descend %.1f leaf %.1f; finish %.1f setup %.1f]", h.tDescend[k] / n / 100.0, h.tLeaf[k] / n / 100.0, h.tFinish[k] / n / 100.0, h.tSetup[k] / n / 100.0 );
+		fprintf( stderr, " [direction octants per chunk %.2f, rays in the chunk's most frequent octant %.3f]", h.octDistinct[k] / n, h.octRays[k] ? (double) h.octMajor[k] / (double) h.octRays[k] : 0.0 );
 		if ( getenv( "RT_PROF_HIST" ) ) for ( int b = 0; b < 64; ++b ) if ( h.chunkHist[k][b] ) fprintf( stderr, " %d:%u", b, h.chunkHist[k][b] );
 		fprintf( stderr, "\n" );
 	}
