@@ -125,6 +125,26 @@ def test_work_buffers_that_turn_out_too_small_are_grown_and_the_levels_run_again
     assert_same_tree(v, t, 10, 3)
 
 
+def test_result_buffers_guessed_from_the_previous_build_of_as_many_triangles():
+    """The device builder allocates the result while the levels run, sized by its previous build of as many triangles
+    (a frame loop rebuilds about the same tree), and checks on the device whether the tree fits: same size again,
+    a much larger tree, a much smaller one, with and without the second (complete) leaf lists."""
+    v, t = random_soup(4000, 17)
+    for depth, prims, prune in ((12, 6, 0.0), (12, 6, 0.0), (24, 2, 0.0), (3, 6, 0.0), (12, 6, 1e-5), (12, 6, 1e-5), (20, 3, 1e-5), (12, 6, 0.0)):
+        host = FlatTree.build(v, t, depth, prims, 2, prune_leaves=prune)
+        dev = DeviceTree.build(v, t, depth, prims, prune_leaves=prune)
+        got = dev.download()
+        assert np.array_equal(np.where((got.nodes["b"] & 3) == 3, 0, got.nodes["a"]), np.where((host.nodes["b"] & 3) == 3, 0, host.nodes["a"]))
+        if prune == 0.0:
+            assert np.array_equal(got.nodes, host.nodes) and _same_floats(got.recs, host.recs) and got.leaf_full is None
+        else:
+            assert got.leaf_full is not None and len(got.recs_all) == 2 * dev.n_recs
+        assert _same_floats(got.shade, host.shade) and dev.depth == host.depth
+        for x in (host, got):
+            x.release()
+        dev.release()
+
+
 def test_planes_that_do_not_ascend_and_nodes_that_span_many_blocks():
     """An infinite coordinate makes the scene box infinite and the candidate planes NaN (no order: the counts are
     taken plane by plane); 300 000 triangles in one node are counted by hundreds of blocks."""
