@@ -7,8 +7,13 @@ import csv, glob, json, os, shutil, subprocess, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 key = sys.argv[3] if len(sys.argv) > 3 else "config3/depth26/leaf12/pruned/gpus1"
 src = os.path.join("gpurun_out", tag)
-shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], f"profiles/{rnd}_kernel_stats.csv")
-ser = glob.glob(src + "/stats_serial/*/*_kernel_stats.csv")
+def newest(pattern):
+    """(results of several runs under one tag pile up in gpurun_out: the latest one counts)"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+shutil.copy(newest(src + "/stats/*/*_kernel_stats.csv")[0], f"profiles/{rnd}_kernel_stats.csv")
+ser = newest(src + "/stats_serial/*/*_kernel_stats.csv")
 if ser:
     shutil.copy(ser[0], f"profiles/{rnd}_kernel_stats_serial.csv")
     shutil.copy(src + "/bench_serial_under_rocprof.json", f"profiles/{rnd}_bench_config3_serial_under_rocprof.json")
