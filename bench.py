@@ -28,13 +28,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# A frame runs on three streams (closest-hit chain + two auxiliary ones) and four frames are in
+# A frame runs on three streams (closest-hit chain + two auxiliary ones) and four to six frames are in
 # flight; with the null stream (the kd-tree builder's) and the collective library's streams a rank
-# uses thirteen to seventeen.  The runtime's default of four hardware queues per process folds several
+# uses up to twenty-one.  The runtime's default of four hardware queues per process folds several
 # streams into one queue, which serialises what is meant to overlap: measured, a frame of two in
-# flight costs 7.2 ms at 8 queues (one stream too few) and 6.8 ms from 10 on.  Must be set before
-# the HIP runtime starts (the machine exports 4, hence an assignment).
-os.environ["GPU_MAX_HW_QUEUES"] = "16"
+# flight costs 7.2 ms at 8 queues (one stream too few) and 6.8 ms from 10 on; six contexts on 16 queues
+# render a 1/8 share in 0.83 ms, on 20 to 24 queues in 0.72 to 0.76 ms (a full frame: no difference).  More
+# streams than queues and streams share queues; and once a process has brought 24 or more hardware queues
+# into being, everything it runs afterwards is slower (eight contexts: 1/8 share 1.2 ms; the fly-through frame
+# after the other workloads 40.7 against 27.3 ms) - hence 22: five contexts of three streams, the checker's
+# three, the null stream and the collective library's.  The streams themselves are reused from workload to
+# workload (stream_for below, and the library's own pool): the runtime deals queues to streams in the order
+# of their creation, and streams that come and go end up sharing a queue with a neighbour.  Must be set
+# before the HIP runtime starts (the machine exports 4, hence an assignment).
+os.environ["GPU_MAX_HW_QUEUES"] = "22"
 
 import numpy as np
 import torch
@@ -62,7 +69,21 @@ TREE_DEPTH, TREE_LEAF = 26, 12
 PRUNE_LEAVES = 1e-5
 ORBIT_FRAMES = 240
 IN_FLIGHT = 4                         # frames in flight (contexts that share the resident scene)
+# ... of a rank that renders a quarter of the frame or less (its passes are short lists that leave most of the chip
+# idle: 1/8 share 0.85 / 0.76 / 0.76 / 0.74 ms with 4 / 5 / 6 / 7 in flight, 1/4 share 1.40 / 1.33 / 1.33 / 1.30 ms; half and
+# full frames gain nothing beyond four)
+IN_FLIGHT_SMALL = 5
 PROFILE_TAG = "profiles/r03"          # the committed profiler summaries the line refers to
+
+_STREAMS = []
+
+
+def stream_for(k):
+    """The k-th frame in flight's stream: one set for the whole process, whatever workload is being rendered."""
+    while len(_STREAMS) <= k:
+        _STREAMS.append(torch.cuda.Stream())
+    return _STREAMS[k]
+
 
 WORKLOADS = {
     "config3": dict(make=scenes.config3, text="1M-triangle displaced sphere + floor, 3840x2160, "
@@ -157,7 +178,7 @@ def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, pl
         plain = FlatTree.build(v, t, depth, leaf) if prune > 0 else None
     slots = []
     for k in range(IN_FLIGHT):
-        st = torch.cuda.Stream()
+        st = stream_for(k)
         r = HipRenderer(local_dev, stream=st.cuda_stream)
         if k == 0:
             r.load_scene(sc, tree)
@@ -249,9 +270,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: consecutive frames alternate between this many contexts (own streams and work "
                          "buffers, one shared scene), so a frame's sparse last passes overlap the next frame's first ones.  "
-                         "0 = 4 (full frame 5.27 / 5.20 ms with 3 / 4 in flight, half 2.84 / 2.76, quarter 1.65 / 1.51, "
-                         "eighth 1.02 / 0.89 / 1.05 ms with 3 / 4 / 5: four contexts of three streams each are as many "
-                         "streams as the hardware queues take without time-slicing)")
+                         "0 = 4, and 5 for a rank that renders a quarter of the frame or less (22 hardware queues: a context "
+                         "takes three)")
     args = ap.parse_args()
 
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
@@ -304,7 +324,9 @@ def main():
     split = world > 1 and not sequence
     pad = rdist.padded_rows(sc.h, rdist.BAND_H, world) if split else sc.h
     def slots_for(parts):
-        return max(1, min(args.in_flight, 4)) if args.in_flight else IN_FLIGHT
+        if args.in_flight:
+            return max(1, min(args.in_flight, 7))
+        return IN_FLIGHT if parts <= 2 else IN_FLIGHT_SMALL
 
     def waves_for(parts, contexts):
         """Waves per CU one traversal pass occupies: all 16 for a frame on its own; with frames in flight 8, and 6 for
@@ -315,8 +337,6 @@ def main():
         return 16 if contexts <= 1 else (8 if parts <= 2 else 6)
 
     n_slots = slots_for(world if split else 1)
-    # (the strong-scaling proxy of a single-rank run renders quarter and eighth shares: one more context for those)
-    n_built = max(n_slots, slots_for(8)) if world == 1 and not sequence and not args.no_proxy and not args.timed_only else n_slots
 
     # ---- one context per frame in flight: own stream, own work buffers, own output and exchange; the scene is
     # resident once and shared
@@ -324,14 +344,16 @@ def main():
         pass
 
     slots = []
-    for k in range(n_built):
+
+    def add_slot(where):
+        k = len(where)
         sl = Slot()
-        sl.stream = torch.cuda.Stream()          # (not the default stream: work on it would wait for, and hold up, the other frame)
+        sl.stream = stream_for(k)                # (not the default stream: work on it would wait for, and hold up, the other frame)
         sl.r = HipRenderer(local_dev, stream=sl.stream.cuda_stream)
         if k == 0:
             sl.r.load_scene(sc, tree)
         else:
-            sl.r.share_scene(slots[0].r, sc)
+            sl.r.share_scene(where[0].r, sc)
         sl.r.set_param(RT_PARAM_OVERLAP, 0 if args.no_overlap else 1)
         # frames in flight: a pass takes half the wave slots of a CU or less, so that the passes of the other frames find
         # room beside it (5.38 against 5.76 ms per step; a frame alone would be faster with all 16: 6.7 against 7.4 ms)
@@ -340,7 +362,10 @@ def main():
             sl.r.set_tile(rdist.BAND_H, world, rank)
         sl.frame_local = torch.zeros((pad, sc.w, 4), dtype=torch.uint8, device=dev)
         sl.comm, sl.frame_full = None, None
-        slots.append(sl)
+        where.append(sl)
+
+    for k in range(n_slots):
+        add_slot(slots)
     torch.cuda.synchronize()                     # buffers were zeroed on torch's default stream
     r = slots[0].r
     rows = r.local_rows
@@ -351,7 +376,7 @@ def main():
     # it decides whether the pruned lists may be used at all (this rank's share of the first frame, every pixel compared
     # on the device); after it, every slot's last timed frame is compared with the checker's frame of the same camera.
     # The checker only exists while it is used: a context's streams take hardware queues, and with more streams in
-    # the process than queues (16) streams share queues and the frames in flight queue up behind each other (step time
+    # the process than queues streams share queues and the frames in flight queue up behind each other (step time
     # 5.54 against 5.20 ms with the checker's three streams left open beside four contexts).
     plain = None
     if not args.timed_only and args.prune_leaves > 0 and len(tree.recs) < ref_refs:
@@ -604,6 +629,11 @@ def main():
     if world == 1 and not sequence and not args.no_proxy and not args.timed_only:
         proxy = {}
         for parts in (2, 4, 8):
+            # (small shares are rendered with more frames in flight: their contexts are only opened now - streams that
+            # exist take hardware queues whether they are used or not)
+            while len(all_slots) < slots_for(parts):
+                add_slot(all_slots)
+                torch.cuda.synchronize()
             use = all_slots[:slots_for(parts)]
             outs = []
             for sl in use:
@@ -614,10 +644,10 @@ def main():
                 use[i % len(use)].r.render(0, d_out=outs[i % len(use)].data_ptr())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(36):
+            for i in range(40):
                 use[i % len(use)].r.render(0, d_out=outs[i % len(use)].data_ptr())
             torch.cuda.synchronize()
-            proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 36 * 1e3, 4)
+            proxy[f"part_0_of_{parts}_ms"] = round((time.perf_counter() - t0) / 40 * 1e3, 4)
             proxy[f"part_0_of_{parts}_frames_in_flight"] = len(use)
             proxy[f"part_0_of_{parts}_waves_per_cu_and_pass"] = waves_for(parts, len(use))
         for sl in all_slots:

@@ -44,6 +44,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "rt_hip.h"
@@ -2195,6 +2196,54 @@ static int upload( rt_hip_ctx *c, DevBuf &b, const void *src, size_t bytes )
 void rt_hip_destroy( rt_hip_ctx *c );
 static int scratch_lookup( int device );      // device address of the allocation-free entry point's work area
 
+// Streams come from a pool per device and flavour and go back to it; none is destroyed before the process ends.  The
+// runtime deals its hardware queues (GPU_MAX_HW_QUEUES of them) to streams in the order the streams are created,
+// whether earlier ones still exist or not: a process that opens and closes contexts would sooner or later find the
+// streams of two contexts that run side by side on one queue, where the frames of one wait for the other's (measured:
+// a workload rendered after others had come and gone, 41 ms per frame against 27 ms).  With the pool a process owns
+// as many streams as it ever used at one time.
+#define RT_MAX_DEVICES 64          // device ordinals the library keeps per-device state for
+namespace {
+struct StreamPool
+{
+	std::mutex m;
+	std::vector<hipStream_t> idle[RT_MAX_DEVICES][2];      // [device][0: blocking flavour (hipStreamCreate), 1: non-blocking]
+};
+StreamPool g_streams;
+
+hipStream_t stream_take( int device, bool nonBlocking )
+{
+	if ( device >= 0 && device < RT_MAX_DEVICES )
+	{
+		std::lock_guard<std::mutex> lk( g_streams.m );
+		auto &v = g_streams.idle[device][nonBlocking ? 1 : 0];
+		if ( !v.empty() )
+		{
+			hipStream_t st = v.back();
+			v.pop_back();
+			return st;
+		}
+	}
+	hipStream_t st = nullptr;
+	const hipError_t e = nonBlocking ? hipStreamCreateWithFlags( &st, hipStreamNonBlocking ) : hipStreamCreate( &st );
+	return e == hipSuccess ? st : nullptr;
+}
+
+void stream_give( int device, bool nonBlocking, hipStream_t st )
+{
+	if ( !st )
+		return;
+	(void) hipStreamSynchronize( st );
+	if ( device < 0 || device >= RT_MAX_DEVICES )
+	{
+		(void) hipStreamDestroy( st );
+		return;
+	}
+	std::lock_guard<std::mutex> lk( g_streams.m );
+	g_streams.idle[device][nonBlocking ? 1 : 0].push_back( st );
+}
+} // namespace
+
 rt_hip_ctx *rt_hip_create( int device )
 {
 	int n = rt_hip_device_count();
@@ -2212,7 +2261,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	c->device = device;
 	c->tag = new SceneTag();
 	hipDeviceProp_t prop;
-	if ( hipGetDeviceProperties( &prop, device ) != hipSuccess || hipStreamCreate( &c->own ) != hipSuccess )
+	if ( hipGetDeviceProperties( &prop, device ) != hipSuccess || ( c->own = stream_take( device, false ) ) == nullptr )
 	{
 		fail( "rt_hip_create: device query / stream creation failed" );
 		scene_tag_release( c->tag );
@@ -2275,7 +2324,7 @@ rt_hip_ctx *rt_hip_create( int device )
 	// (a frame never completed in about one run out of three).
 	bool ok = true;
 	for ( auto &a : c->aux )
-		ok = ok && hipStreamCreateWithFlags( &a, hipStreamNonBlocking ) == hipSuccess;
+		ok = ok && ( a = stream_take( device, true ) ) != nullptr;
 	for ( int k = 0; k < RT_MAX_SLOTS && ok; ++k )
 		ok = hipEventCreateWithFlags( &c->evHit[k], hipEventDisableTiming ) == hipSuccess
 			&& hipEventCreateWithFlags( &c->evLit[k], hipEventDisableTiming ) == hipSuccess;
@@ -2294,7 +2343,7 @@ void rt_hip_destroy( rt_hip_ctx *c )
 		return;
 	(void) hipSetDevice( c->device );
 	(void) hipStreamSynchronize( c->stream );
-	for ( auto &a : c->aux ) if ( a ) { (void) hipStreamSynchronize( a ); (void) hipStreamDestroy( a ); }
+	for ( auto &a : c->aux ) stream_give( c->device, true, a );
 	for ( int k = 0; k < RT_MAX_SLOTS; ++k )
 	{
 		if ( c->evHit[k] ) (void) hipEventDestroy( c->evHit[k] );
@@ -2306,15 +2355,15 @@ void rt_hip_destroy( rt_hip_ctx *c )
 		if ( b->p ) (void) hipFree( b->p );
 	if ( c->haveEvents )
 		for ( auto &f : c->ev ) for ( auto &e : f ) (void) hipEventDestroy( e );
-	if ( c->own ) (void) hipStreamDestroy( c->own );
+	stream_give( c->device, false, c->own );
 	if ( c->tag ) c->tag->gen.store( ~0ull );        // borrowers: the scene is gone
 	scene_tag_release( c->tag );
 	scene_tag_release( c->lender );
 	delete c;
 }
 
-// A context that runs on the caller's stream gives its own stream back: every stream of the process takes
-// a place among the runtime's hardware queues, and streams beyond their number share queues with others.
+// A context that runs on the caller's stream gives its own stream back to the pool: every stream of the process
+// takes a place among the runtime's hardware queues, and streams beyond their number share queues with others.
 int rt_hip_set_stream( rt_hip_ctx *c, void *s )
 {
 	if ( !c ) return fail( "null context" );
@@ -2322,15 +2371,13 @@ int rt_hip_set_stream( rt_hip_ctx *c, void *s )
 	HIPCHK( hipStreamSynchronize( c->stream ) );
 	if ( s )
 	{
-		if ( c->own )
-		{
-			HIPCHK( hipStreamDestroy( c->own ) );
-			c->own = nullptr;
-		}
+		stream_give( c->device, false, c->own );
+		c->own = nullptr;
 		c->stream = (hipStream_t) s;
 		return 0;
 	}
-	if ( !c->own ) HIPCHK( hipStreamCreate( &c->own ) );
+	if ( !c->own && ( c->own = stream_take( c->device, false ) ) == nullptr )
+		return fail( "rt_hip_set_stream: stream creation failed" );
 	c->stream = c->own;
 	return 0;
 }
@@ -3002,7 +3049,6 @@ static_assert( NoallocLayout::total <= RT_HIP_NOALLOC_BYTES, "RT_HIP_NOALLOC_BYT
 static __device__ __align__( 256 ) unsigned char scratch[RT_HIP_NOALLOC_BYTES];
 
 // device address of `scratch` on each GPU (the array's name is only a handle on the host)
-#define RT_MAX_DEVICES 64
 static unsigned char *g_scratch_ptr[RT_MAX_DEVICES] = {};
 // the allocation-free frame enqueued last on each GPU: its stream, and an event behind it
 // (created with the scratch look-up, i.e. at set-up, not by the entry point)

@@ -59,7 +59,7 @@ def test_single_rank_line_has_what_the_contract_asks_for():
     assert all(0 < wall[k] <= b["ms_per_step"] * 1.02 for k in ("closest", "shadow", "shade"))
     assert wall["closest"] <= b["kernel_ms_per_frame_rank0"]["closest"] * 1.001
     p = b["strong_scaling_proxy"]
-    assert p["part_0_of_8_frames_in_flight"] == 4 and p["part_0_of_2_frames_in_flight"] == 4
+    assert p["part_0_of_8_frames_in_flight"] == 5 and p["part_0_of_2_frames_in_flight"] == 4     # (small shares: one more in flight)
     assert set(r["evidence"]) >= {"achieved_isolated / avg_launch_ms_isolated", "avg_launch_ms"}
     assert 0 < p["part_0_of_8_ms"] < p["part_0_of_2_ms"] < 1.2 * b["ms_per_step"]
     t = run_bench(1, 0, ["--timed-only"])
