@@ -73,6 +73,17 @@ IN_FLIGHT = 4                         # frames in flight (contexts that share th
 # idle: 1/8 share 0.85 / 0.76 / 0.76 / 0.74 ms with 4 / 5 / 6 / 7 in flight, 1/4 share 1.40 / 1.33 / 1.33 / 1.30 ms; half and
 # full frames gain nothing beyond four)
 IN_FLIGHT_SMALL = 5
+SMALL_FRAME = 2_200_000               # pixels: a quarter of a 4K frame, a 1080p frame
+
+
+def in_flight_for(pixels, parts):
+    """Frames in flight for a rank that renders `pixels` pixels per frame as one of `parts` ranks: four; five for small
+    frames; six for small frames on a single rank (no collective library whose streams want queues too: the 1080p
+    workload 0.66 / 0.63 / 0.60 ms per step with 4 / 5 / 6)."""
+    if pixels > SMALL_FRAME:
+        return IN_FLIGHT
+    return IN_FLIGHT_SMALL + (1 if parts == 1 else 0)
+
 PROFILE_TAG = "profiles/r03"          # the committed profiler summaries the line refers to
 
 _STREAMS = []
@@ -176,8 +187,9 @@ def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, pl
     if own:
         tree = FlatTree.build(v, t, depth, leaf, prune_leaves=prune)
         plain = FlatTree.build(v, t, depth, leaf) if prune > 0 else None
+    n_fl = in_flight_for(sc.w * sc.h, 1)
     slots = []
-    for k in range(IN_FLIGHT):
+    for k in range(n_fl):
         st = stream_for(k)
         r = HipRenderer(local_dev, stream=st.cuda_stream)
         if k == 0:
@@ -190,18 +202,18 @@ def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, pl
     last = {}
 
     def step(i):
-        r, out = slots[i % IN_FLIGHT]
+        r, out = slots[i % n_fl]
         if sequence:
             r.set_camera(cam(i))
         r.render(0, d_out=out.data_ptr())
-        last[i % IN_FLIGHT] = i
+        last[i % n_fl] = i
 
     torch.cuda.synchronize()
-    for i in range(IN_FLIGHT):
+    for i in range(n_fl):
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(IN_FLIGHT, IN_FLIGHT + steps):
+    for i in range(n_fl, n_fl + steps):
         step(i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -222,13 +234,13 @@ def side_workload(name, local_dev, dev, depth, leaf, prune, steps, tree=None, pl
         ok = ok and bool(torch.equal(slots[k][1], want))
     rays = 0
     r0 = slots[0][0]
-    for i in range(IN_FLIGHT, IN_FLIGHT + steps) if sequence else [0]:
+    for i in range(n_fl, n_fl + steps) if sequence else [0]:
         if sequence:
             r0.set_camera(cam(i))
         r0.render(0, d_out=slots[0][1].data_ptr())
         st = r0.stats()
         rays += (st["raysClosest"] + st["raysShadow"]) * (1 if sequence else steps)
-    out = {"workload": f"{name}: {wl['text']}", "steps": steps, "warmup": IN_FLIGHT, "frames_in_flight": IN_FLIGHT,
+    out = {"workload": f"{name}: {wl['text']}", "steps": steps, "warmup": n_fl, "frames_in_flight": n_fl,
            "ms_per_step": round(elapsed / steps * 1e3, 4), "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
            "rays_per_step": int(rays / steps), "frames_verified": ok,
            "kd_tree": {"max_depth": depth, "max_prims_in_leaf": leaf, "triangle_refs": int(len(tree.recs)),
@@ -326,7 +338,7 @@ def main():
     def slots_for(parts):
         if args.in_flight:
             return max(1, min(args.in_flight, 7))
-        return IN_FLIGHT if parts <= 2 else IN_FLIGHT_SMALL
+        return in_flight_for(sc.w * sc.h // (parts if not sequence else 1), parts)
 
     def waves_for(parts, contexts):
         """Waves per CU one traversal pass occupies: all 16 for a frame on its own; with frames in flight 8, and 6 for
