@@ -223,6 +223,76 @@ def test_render_pipe_api_matches_and_consumes_the_scene():
     rp.cleanup()
 
 
+def test_tree_cache_notices_every_kind_of_change():
+    """RT_PARAM_TREE_CACHE keeps the tree while the geometry handed to the pipe is the same, word for word; its change
+    detector is fed while the triangles are added.  Every frame of a pipe with the cache on equals the frame of a
+    fresh pipe without it: unchanged geometry, some vertices moved, back again, one index
+    changed, the material slot changed, the same mesh added in two calls, an odd number of triangles, and the cache
+    switched on when the geometry had already been added."""
+    import copy
+    base = scenes.sphere_scene(40, 30, 200, 120, reflect=0.4)
+    base.materials[1] = T.make_material((1.0, 0.2, 0.7, 0.3), (0.0, 0.05, 0.05, 0.05), (0.0, 0.6, 0.6, 0.6), (20.0, 0.3, 0.3, 0.3),
+                                        (0.0, 0.0, 0.0, 0.0), 0.05, 1.0)
+
+    def variant(kind):
+        sc = copy.deepcopy(base)
+        m = sc.meshes[0]
+        if kind == "vertex":
+            m.verts["pos"]["y"][600:1000] -= 4.0
+        elif kind == "index":
+            m.tris["pV2"][1000:1400] = m.tris["pV2"][0]
+        elif kind == "group":
+            m.group = 1
+        elif kind == "odd":
+            m.tris = m.tris[:-1].copy()
+        return sc
+
+    def add(rp, sc, two_calls=False):
+        for k in sorted(sc.materials):
+            rp.add_material(sc.materials[k], k)
+        for l in sc.lights:
+            rp.add_light(l)
+        for m in sc.meshes:
+            if two_calls:
+                half = len(m.tris) // 2 + 1
+                rp.add_triangles(m.verts, m.tris, 0, 0, len(m.verts), half, m.group)
+                rp.add_triangles(m.verts, m.tris, 0, half, len(m.verts), len(m.tris) - half, m.group)
+            else:
+                rp.mesh_add(m)
+
+    def fresh(sc, two_calls=False):
+        rp = RenderPipe(sc.w, sc.h)
+        rp.set_camera(sc.camera)
+        add(rp, sc, two_calls)
+        img = rp.draw().copy()
+        rp.cleanup()
+        return img
+
+    rp = RenderPipe(base.w, base.h)
+    rp.set_camera(base.camera)
+    rp.set_param(RT_PARAM_TREE_CACHE, 1)
+    seen = []
+    for kind, two in (("base", False), ("base", False), ("vertex", False), ("base", False), ("index", False), ("group", False),
+                      ("base", True), ("base", True), ("odd", False), ("odd", False), ("base", False)):
+        sc = variant(kind)
+        add(rp, sc, two)
+        img = rp.draw().copy()
+        assert np.array_equal(img, fresh(sc, two)), (kind, two)
+        seen.append(img)
+    assert not np.array_equal(seen[0], seen[2]) and not np.array_equal(seen[0], seen[4]) and not np.array_equal(seen[0], seen[5])
+    rp.cleanup()
+    # switched on with the geometry already there, and off again
+    rp = RenderPipe(base.w, base.h)
+    rp.set_camera(base.camera)
+    for kind in ("base", "vertex", "vertex"):
+        sc = variant(kind)
+        add(rp, sc)
+        rp.set_param(RT_PARAM_TREE_CACHE, 1)
+        assert np.array_equal(rp.draw(), fresh(sc)), kind
+        rp.set_param(RT_PARAM_TREE_CACHE, 0)
+    rp.cleanup()
+
+
 def test_render_pipe_kdtree_build_and_params():
     sc, _, _ = IMG["sphere16k_reflect"]
     rp = RenderPipe(sc.w, sc.h)
