@@ -135,6 +135,10 @@ int  rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_flat *out )
 const char *rt_kdtree_device_last_error( void );
 /* the builder keeps its work buffers (per thread and device) for the next build; this frees them */
 void rt_kdtree_device_trim( void );
+/* The four device buffers of a tree that nothing reads any more (any of them may be NULL), for the next build of this
+ * thread on the current device to write its result into, instead of hipFree: a frame loop that rebuilds its tree
+ * spent a millisecond and more per frame freeing 0.4 GB.  One set is kept; rt_kdtree_device_trim frees it. */
+void rt_kdtree_device_recycle( void *nodes, void *recs, void *shade, void *leafFull );
 
 #ifdef __cplusplus
 }

@@ -1409,12 +1409,38 @@ struct Scratch
 	DVec verts, tris, ext, refsA, refsB, tabA, tabB, hist, sums, info, leafPool, sub, order, geom, state;
 	Caps caps = { 0u, 0u, 0u, 0u };
 	uint32_t lastNT = 0xffffffffu, lastNodes = 0, lastRecs = 0;      // what the previous build of this thread came to
+	// buffers of a tree that is no longer in use, kept for the next result (rt_kdtree_device_recycle): [0] nodes, [1] records,
+	// [2] shading records, [3] complete-list table, with their sizes as allocated
+	void *spare[4] = { nullptr, nullptr, nullptr, nullptr };
+	size_t spareBytes[4] = { 0, 0, 0, 0 };
+	void drop_spare()
+	{
+		for ( int k = 0; k < 4; ++k )
+		{
+			if ( spare[k] ) (void) hipFree( spare[k] );
+			spare[k] = nullptr;
+			spareBytes[k] = 0;
+		}
+	}
+	// `bytes` of device memory: the spare buffer of that kind if it is large enough (and not wastefully so), else new
+	hipError_t take( int kind, void **p, size_t bytes )
+	{
+		if ( spare[kind] && spareBytes[kind] >= bytes && spareBytes[kind] <= 2 * bytes + ( 1u << 20 ) )
+		{
+			*p = spare[kind];
+			spare[kind] = nullptr;
+			spareBytes[kind] = 0;
+			return hipSuccess;
+		}
+		return hipMalloc( p, bytes );
+	}
 	bool histClean = false;      // every entry of `hist` is zero (each level leaves it so; a build that failed half-way may not)
 	void *pinned = nullptr;      // BuildState + GeomInfo as the host reads them
 	void release()
 	{
 		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &tabA, &tabB, &hist, &sums, &info, &leafPool, &sub, &order, &geom, &state } )
 			v->release();
+		drop_spare();
 		if ( pinned ) (void) hipHostFree( pinned );
 		pinned = nullptr;
 		caps = Caps{ 0u, 0u, 0u, 0u };
@@ -1467,6 +1493,35 @@ extern "C" void rt_kdtree_device_trim( void )
 	}
 }
 
+extern "C" void rt_kdtree_device_recycle( void *nodes, void *recs, void *shade, void *leafFull )
+{
+	void *in[4] = { nodes, recs, shade, leafFull };
+	int dev = 0;
+	const bool here = hipGetDevice( &dev ) == hipSuccess && ( g_scratchDev == dev || g_scratchDev < 0 );
+	if ( here )
+		g_scratchDev = dev;
+	Scratch &S = g_scratch;
+	for ( int k = 0; k < 4; ++k )
+	{
+		if ( !in[k] )
+			continue;
+		void *base = nullptr;
+		size_t size = 0;
+		// (the size as allocated; a pointer into the middle of an allocation, or one this runtime does not know, is freed)
+		if ( here && hipMemGetAddressRange( &base, &size, in[k] ) == hipSuccess && base == in[k] && size > S.spareBytes[k] )
+		{
+			if ( S.spare[k] ) (void) hipFree( S.spare[k] );
+			S.spare[k] = in[k];
+			S.spareBytes[k] = size;
+		}
+		else
+		{
+			(void) hipGetLastError();
+			(void) hipFree( in[k] );
+		}
+	}
+}
+
 extern "C" void rt_kdtree_device_release( rt_kdtree_device *t )
 {
 	if ( !t )
@@ -1506,9 +1561,10 @@ static void free_result( rt_kdtree_device *out, ResultBufs &fin )
 
 static int alloc_result( rt_kdtree_device *out, size_t nodes, size_t recs, bool two, ResultBufs &fin )
 {
-	hipError_t ea = hipMalloc( &out->nodes, sizeof( rt_hip_kdnode ) * ( nodes ? nodes : 1 ) );
-	if ( ea == hipSuccess ) ea = hipMalloc( &out->recs, sizeof( rt_hip_trirec ) * ( recs * ( two ? 2 : 1 ) + 1 ) );
-	if ( ea == hipSuccess && two ) ea = hipMalloc( &out->leafFull, sizeof( rt_hip_leaf_full ) * ( nodes ? nodes : 1 ) );
+	Scratch &S = g_scratch;
+	hipError_t ea = S.take( 0, &out->nodes, sizeof( rt_hip_kdnode ) * ( nodes ? nodes : 1 ) );
+	if ( ea == hipSuccess ) ea = S.take( 1, &out->recs, sizeof( rt_hip_trirec ) * ( recs * ( two ? 2 : 1 ) + 1 ) );
+	if ( ea == hipSuccess && two ) ea = S.take( 3, &out->leafFull, sizeof( rt_hip_leaf_full ) * ( nodes ? nodes : 1 ) );
 	if ( ea != hipSuccess )
 	{
 		snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );
@@ -1671,7 +1727,7 @@ static int build_device( const rt_vertex *verts, const rt_triangle *tris, uint64
 		// (a frame loop rebuilds about the same tree every frame; allocating 0.4 GB takes 0.3 ms, a twelfth of a build).
 		if ( !out->shade )
 		{
-			hipError_t ea = hipMalloc( &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
+			hipError_t ea = S.take( 2, &out->shade, sizeof( rt_hip_trishade ) * ( nT ? nT : 1 ) );
 			if ( ea != hipSuccess )
 			{
 				snprintf( g_gpu_build_err, sizeof( g_gpu_build_err ), "allocating the tree failed: %s", hipGetErrorString( ea ) );

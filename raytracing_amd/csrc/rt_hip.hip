@@ -2471,13 +2471,19 @@ int rt_hip_adopt_tree( rt_hip_ctx *c, rt_kdtree_device *t )
 	void *src[3] = { t->nodes, t->recs, t->shade };
 	const size_t bytes[3] = { t->nNodes * sizeof( rt_hip_kdnode ), ( t->nRecs + ( t->leafFull ? t->nRecsFull : 0 ) + 1 ) * sizeof( rt_hip_trirec ),
 		( t->nTris ? t->nTris : 1 ) * sizeof( rt_hip_trishade ) };
+	// The old tree: to the builder for its next result when nobody borrows this context's scene (a frame loop that
+	// rebuilds every frame would otherwise free 0.4 GB per frame), else freed - hipFree waits for the whole device.
+	void *old[4] = { c->nodes.p, c->recs.p, c->shade.p, c->leafFull.p };
+	if ( c->tag && c->tag->refs.load() == 1 )
+		rt_kdtree_device_recycle( old[0], old[1], old[2], old[3] );
+	else
+		for ( void *p : old )
+			if ( p ) HIPCHK( hipFree( p ) );
 	for ( int i = 0; i < 3; ++i )
 	{
-		if ( dst[i]->p ) HIPCHK( hipFree( dst[i]->p ) );
 		dst[i]->p = src[i];
 		dst[i]->cap = bytes[i];
 	}
-	if ( c->leafFull.p ) HIPCHK( hipFree( c->leafFull.p ) );
 	c->leafFull.p = t->leafFull;
 	c->leafFull.cap = t->leafFull ? t->nNodes * sizeof( rt_hip_leaf_full ) : 0;
 	c->S.leafFull = (const uint2 *) c->leafFull.p;
