@@ -152,6 +152,13 @@ int  rt_hip_adopt_tree( rt_hip_ctx *c, struct _rt_kdtree_device *t );
 /* build on the context's device and stream from HOST geometry and install the result */
 int  rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, int maxDepth, int maxPrims );
+/* Geometry on its way to the device while the caller is still adding to it (no reference counterpart; see
+ * rt_kdtree_device_stage in rt_kdtree.h): what of the leading nVerts / nTris entries earlier calls have not copied
+ * is copied now, asynchronously on the context's stream, and the next rt_hip_build_tree of this context - which must
+ * be given arrays with the same leading entries, unchanged - copies only the rest.  rt_hip_unstage_geometry: the next
+ * rt_hip_build_tree is for other geometry after all. */
+int  rt_hip_stage_geometry( rt_hip_ctx *c, const rt_vertex *verts, uint64_t nVerts, const rt_triangle *tris, uint64_t nTris );
+void rt_hip_unstage_geometry( rt_hip_ctx *c );
 int  rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n );
 int  rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n );
 int  rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n );

@@ -69,6 +69,7 @@ typedef struct _rt_kdtree_build_opts
 	float sahStop;
 	int   allAxes;
 	float pruneLeaves;
+	uint64_t stageTicket;      /* GPU builder only: the geometry was (partly) copied ahead, see rt_kdtree_device_stage; 0 = not */
 } rt_kdtree_build_opts;
 
 int  rt_kdtree_build_flat_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
@@ -130,6 +131,16 @@ int  rt_kdtree_build_device( const rt_vertex *verts, const rt_triangle *tris, ui
 int  rt_kdtree_build_device_ex( const rt_vertex *verts, const rt_triangle *tris, uint64_t vertexCount,
 	uint64_t trianglesCount, const rt_kdtree_build_opts *opts, void *hipStream, rt_kdtree_device *out );
 void rt_kdtree_device_release( rt_kdtree_device *t );
+/* Geometry on its way to the device while the caller is still putting it together (no reference counterpart): copies
+ * those of the leading nVerts vertices and nTris triangles of the arrays that earlier calls with this ticket have
+ * not copied yet, asynchronously on hipStream, into the builder's input buffers of this thread and the current
+ * device.  *ticket == 0 starts over and receives a fresh ticket; the build that is then given arrays with the same
+ * leading entries and that ticket (rt_kdtree_build_opts.stageTicket) copies the rest only.  The entries handed
+ * over must not change before that build returns.  When the buffers have gone to other geometry in the meantime
+ * (another staging or build of the thread), *ticket comes back 0 and nothing was copied: the build copies everything,
+ * as it does for a ticket it does not know.  Returns 0, or 1 / 10 as the builds do. */
+int  rt_kdtree_device_stage( uint64_t *ticket, const rt_vertex *verts, uint64_t nVerts, const rt_triangle *tris,
+	uint64_t nTris, void *hipStream );
 /* copy a device tree to host arrays (malloc'ed; rt_kdtree_flat_release frees them) */
 int  rt_kdtree_device_download( const rt_kdtree_device *t, rt_kdtree_flat *out );
 const char *rt_kdtree_device_last_error( void );

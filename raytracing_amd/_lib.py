@@ -49,7 +49,8 @@ class DeviceTreeStruct(C.Structure):   # rt_kdtree_device
 
 class BuildOpts(C.Structure):     # rt_kdtree_build_opts
     _fields_ = [("maxDepth", C.c_int), ("maxPrims", C.c_int), ("threads", C.c_int),
-                ("sahStop", C.c_float), ("allAxes", C.c_int), ("pruneLeaves", C.c_float)]
+                ("sahStop", C.c_float), ("allAxes", C.c_int), ("pruneLeaves", C.c_float),
+                ("stageTicket", C.c_uint64)]
 
 
 class RenderPipeStruct(C.Structure):   # rt_render_pipe

@@ -1436,8 +1436,19 @@ struct Scratch
 	}
 	bool histClean = false;      // every entry of `hist` is zero (each level leaves it so; a build that failed half-way may not)
 	void *pinned = nullptr;      // BuildState + GeomInfo as the host reads them
+	// geometry copied ahead of its build (rt_kdtree_device_stage): the ticket that names it, how many leading entries
+	// of verts / tris hold it, and an event behind the last of its copies for a build or staging on another stream
+	uint64_t stageTicket = 0, stagedV = 0, stagedT = 0;
+	hipStream_t stageStream = nullptr;
+	hipEvent_t stageDone = nullptr;
+	bool stagePending = false;
+	void forget_staged() { stageTicket = 0; stagedV = stagedT = 0; }
 	void release()
 	{
+		forget_staged();
+		stagePending = false;
+		if ( stageDone ) (void) hipEventDestroy( stageDone );      // (hipFree below waits for the copies themselves)
+		stageDone = nullptr;
 		for ( DVec *v : { &verts, &tris, &ext, &refsA, &refsB, &tabA, &tabB, &hist, &sums, &info, &leafPool, &sub, &order, &geom, &state } )
 			v->release();
 		drop_spare();
@@ -1491,6 +1502,67 @@ extern "C" void rt_kdtree_device_trim( void )
 		}
 		g_scratchDev = -1;
 	}
+}
+
+// the scratch of this thread follows the current device
+static int scratch_on_current_device()
+{
+	int dev = 0;
+	GCHK( hipGetDevice( &dev ) );
+	if ( g_scratchDev != dev )
+	{
+		g_scratch.release();
+		g_scratchDev = dev;
+	}
+	return 0;
+}
+
+// copies staged on another stream come first: they write the buffers this stream is about to write
+static int wait_for_staged( Scratch &S, hipStream_t s )
+{
+	if ( S.stagePending && S.stageStream != s )
+		GCHK( hipStreamWaitEvent( s, S.stageDone, 0 ) );
+	return 0;
+}
+
+extern "C" int rt_kdtree_device_stage( uint64_t *ticket, const rt_vertex *verts, uint64_t nVerts, const rt_triangle *tris,
+	uint64_t nTris, void *hipStream )
+{
+	thread_local uint64_t lastTicket = 0;
+	if ( !ticket || ( nVerts && !verts ) || ( nTris && !tris ) || nTris >= ( 1ull << 30 ) )
+		return 1;
+	g_gpu_build_err[0] = 0;
+	if ( int rc = scratch_on_current_device() ) return rc;
+	Scratch &S = g_scratch;
+	hipStream_t s = (hipStream_t) hipStream;
+	if ( *ticket == 0 )
+	{
+		S.forget_staged();
+		S.stageTicket = *ticket = ++lastTicket;
+	}
+	else if ( *ticket != S.stageTicket || nVerts < S.stagedV || nTris < S.stagedT )
+	{
+		// somebody else's geometry lies in the buffers by now, or the arrays shrank: the build will copy everything
+		if ( *ticket == S.stageTicket )
+			S.forget_staged();
+		*ticket = 0;
+		return 0;
+	}
+	if ( int rc = wait_for_staged( S, s ) ) return rc;
+	if ( !S.stageDone )
+		GCHK( hipEventCreateWithFlags( &S.stageDone, hipEventDisableTiming ) );
+	if ( int rc = S.verts.reserve( sizeof( rt_vertex ) * ( nVerts ? nVerts : 1 ), s, sizeof( rt_vertex ) * S.stagedV ) ) return rc;
+	if ( int rc = S.tris.reserve( sizeof( rt_triangle ) * ( nTris ? nTris : 1 ), s, sizeof( rt_triangle ) * S.stagedT ) ) return rc;
+	if ( nVerts > S.stagedV )
+		GCHK( hipMemcpyAsync( S.verts.as<rt_vertex>() + S.stagedV, verts + S.stagedV, sizeof( rt_vertex ) * ( nVerts - S.stagedV ), hipMemcpyHostToDevice, s ) );
+	if ( nTris > S.stagedT )
+		GCHK( hipMemcpyAsync( S.tris.as<rt_triangle>() + S.stagedT, tris + S.stagedT, sizeof( rt_triangle ) * ( nTris - S.stagedT ), hipMemcpyHostToDevice, s ) );
+	S.stagedV = nVerts;
+	S.stagedT = nTris;
+	GCHK( hipEventRecord( S.stageDone, s ) );
+	S.stageStream = s;
+	S.stagePending = true;
+	return 0;
 }
 
 extern "C" void rt_kdtree_device_recycle( void *nodes, void *recs, void *shade, void *leafFull )
@@ -1617,13 +1689,7 @@ static int build_device( const rt_vertex *verts, const rt_triangle *tris, uint64
 	// Work buffers are kept between builds of one thread on one device (a frame
 	// loop rebuilds a tree of about the same size every frame; allocating and
 	// freeing them took as long as all the kernels); rt_kdtree_device_trim frees them.
-	int dev = 0;
-	GCHK( hipGetDevice( &dev ) );
-	if ( g_scratchDev != dev )
-	{
-		g_scratch.release();
-		g_scratchDev = dev;
-	}
+	if ( int rc = scratch_on_current_device() ) return rc;
 	const bool TT = getenv( "RT_KD_TIMING" ) != nullptr;      // (development aid: host time at which each phase was reached, to stderr)
 	auto t0_ = std::chrono::steady_clock::now();
 	auto stamp = [&]( const char *what ) { if ( TT ) { fprintf( stderr, "  %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>( std::chrono::steady_clock::now() - t0_ ).count() ); } };
@@ -1636,10 +1702,21 @@ static int build_device( const rt_vertex *verts, const rt_triangle *tris, uint64
 	// inputs; the index check, the highest material slot and the scene box are
 	// taken from the device copy (a host pass over 1 M triangles and their
 	// vertices costs 2 ms, more than a quarter of the whole build)
-	if ( int rc = S.verts.reserve( sizeof( rt_vertex ) * ( vertexCount ? vertexCount : 1 ), s ) ) return rc;
-	if ( int rc = S.tris.reserve( sizeof( rt_triangle ) * ( nT ? nT : 1 ), s ) ) return rc;
-	if ( vertexCount ) GCHK( hipMemcpyAsync( S.verts.p, verts, sizeof( rt_vertex ) * vertexCount, hipMemcpyHostToDevice, s ) );
-	if ( nT ) GCHK( hipMemcpyAsync( S.tris.p, tris, sizeof( rt_triangle ) * nT, hipMemcpyHostToDevice, s ) );
+	// (what rt_kdtree_device_stage has copied already, if it is this build's geometry, stays where it is)
+	if ( int rc = wait_for_staged( S, s ) ) return rc;
+	uint64_t haveV = 0, haveT = 0;
+	if ( opts->stageTicket && opts->stageTicket == S.stageTicket && S.stagedV <= vertexCount && S.stagedT <= nT )
+	{
+		haveV = S.stagedV;
+		haveT = S.stagedT;
+	}
+	S.forget_staged();
+	if ( int rc = S.verts.reserve( sizeof( rt_vertex ) * ( vertexCount ? vertexCount : 1 ), s, sizeof( rt_vertex ) * haveV ) ) return rc;
+	if ( int rc = S.tris.reserve( sizeof( rt_triangle ) * ( nT ? nT : 1 ), s, sizeof( rt_triangle ) * haveT ) ) return rc;
+	if ( vertexCount > haveV )
+		GCHK( hipMemcpyAsync( S.verts.as<rt_vertex>() + haveV, verts + haveV, sizeof( rt_vertex ) * ( vertexCount - haveV ), hipMemcpyHostToDevice, s ) );
+	if ( nT > haveT )
+		GCHK( hipMemcpyAsync( S.tris.as<rt_triangle>() + haveT, tris + haveT, sizeof( rt_triangle ) * ( nT - haveT ), hipMemcpyHostToDevice, s ) );
 	stamp( "input copies enqueued" );
 	if ( TT ) { (void) hipStreamSynchronize( s ); stamp( "input copies done" ); }
 	if ( int rc = S.ext.reserve( 6 * sizeof( float ) * ( nT ? nT : 1 ), s ) ) return rc;

@@ -148,17 +148,46 @@ struct rt_pipe_impl
 	// in cache then: a pass of its own over 44 MB of unchanged geometry took 6 ms, twice the GPU build it saves)
 	GeomHash adding;
 	bool addingValid = true;         // every add_triangles call since the last draw went into `adding`
+	// Geometry goes to the device while it is being added, when the draw is going to build its tree there and is not
+	// going to reuse the last one (a 1 M-triangle scene is 44 MB: 0.8 ms on the bus that the draw would wait for):
+	// how many vertices / triangles have been handed to rt_hip_stage_geometry since the last draw
+	size_t stagedV = 0, stagedT = 0;
+	bool staging = false;
 	rt_kdtree_flat lastInfo;          // counts of the tree on the device (arrays released)
 };
 
 static int g_device = 0;
 static const size_t GPU_BUILD_MIN = 8192;
+static const size_t STAGE_BYTES = 4u << 20;      // geometry goes to the device in pieces of this size while it is added
+static const size_t STAGE_TRIS = STAGE_BYTES / sizeof( rt_triangle );
 
 static void die_hip( const char *what )
 {
 	fprintf( stderr, "rt: %s: %s\n", what, rt_hip_last_error() );
 	fflush( stderr );
 	exit( -3 );
+}
+
+// Hands what has been added since the last call to the device, once it is a piece worth a copy of its own.
+static void stage_added( rt_pipe_impl *im )
+{
+	if ( im->gpuBuild == 0 || im->treeCache || im->tris.size() < GPU_BUILD_MIN )
+		return;
+	const size_t fresh = ( im->verts.size() - im->stagedV ) * sizeof( rt_vertex ) + ( im->tris.size() - im->stagedT ) * sizeof( rt_triangle );
+	if ( fresh < STAGE_BYTES )
+		return;
+	if ( rt_hip_stage_geometry( im->hip, im->verts.data(), im->verts.size(), im->tris.data(), im->tris.size() ) )
+		die_hip( "geometry upload" );
+	im->stagedV = im->verts.size();
+	im->stagedT = im->tris.size();
+	im->staging = true;
+}
+
+// Copies on their way read the geometry arrays: before the arrays move or go, they have to be done.
+static void staged_copies_done( rt_pipe_impl *im )
+{
+	if ( im->staging && rt_hip_sync( im->hip ) )
+		die_hip( "geometry upload" );
 }
 
 static rt_pipe_impl *impl_of( rt_render_pipe *pRp )
@@ -201,6 +230,13 @@ void rt_init_buffers( rt_render_pipe *pRp )
 	pRp->triangleBlocks = pRp->vertexBlocks = pRp->materialBlocks = 1;
 	pRp->primsEnd = pRp->lightsEnd = 0;
 	pRp->primsCount = pRp->lightsCount = pRp->trianglesCount = pRp->vertexCount = 0;
+	if ( im->staging )
+	{
+		staged_copies_done( im );
+		rt_hip_unstage_geometry( im->hip );
+		im->staging = false;
+	}
+	im->stagedV = im->stagedT = 0;
 	im->verts.clear();
 	im->tris.clear();
 	im->adding.reset();
@@ -331,20 +367,35 @@ void rt_render_pipe_add_triangles( rt_render_pipe *pRp, rt_vertex *pV, rt_triang
 		grow_blocks( &pRp->vertexBlocks, VERTEX_IN_BLOCK * sizeof( rt_vertex ), sizeof( rt_vertex ) * vCount );
 
 	const rt_ulong base = pRp->vertexCount;
+	if ( im->verts.size() + vCount > im->verts.cap || im->tris.size() + tCount > im->tris.cap )
+		staged_copies_done( im );          // (the arrays are about to move)
 	im->verts.append( pV + vOffset, vCount );
-	rt_triangle *dst = im->tris.grow( tCount );
-	if ( im->treeCache && im->addingValid )
+	const bool hashed = im->treeCache && im->addingValid;
+	if ( hashed )
 	{
-		// the same loop, every word written also goes into the change detector (vertices first, as they lie in memory)
-		GeomHash &H = im->adding;
-		H.add( (const uint64_t *) ( pV + vOffset ), vCount * ( sizeof( rt_vertex ) / 8 ) );
-		H.align();
+		// every word written also goes into the change detector (vertices first, as they lie in memory)
+		im->adding.add( (const uint64_t *) ( pV + vOffset ), vCount * ( sizeof( rt_vertex ) / 8 ) );
+		im->adding.align();
+	}
+	else
+		im->addingValid = false;
+	stage_added( im );
+	im->tris.reserve( im->tris.size() + tCount );
+	// (in pieces, so that the first of a large mesh is on the bus while the next is being copied)
+	for ( rt_ulong done = 0; done < tCount; )
+	{
+		const rt_ulong n = tCount - done < (rt_ulong) STAGE_TRIS ? tCount - done : (rt_ulong) STAGE_TRIS;
+		const rt_triangle *src = pTr + tOffset + done;
+		rt_triangle *dst = im->tris.grow( n );
 		rt_ulong i = 0;
+		if ( hashed )
 		{
-			for ( ; i + 2 <= tCount; i += 2 )
+			// (a piece holds an even number of triangles unless it is the last: 8 words per pair keep the lanes in step)
+			GeomHash &H = im->adding;
+			for ( ; i + 2 <= n; i += 2 )
 				for ( int u = 0; u < 2; ++u )
 				{
-					const rt_triangle &s = pTr[i + u + tOffset];
+					const rt_triangle &s = src[i + u];
 					rt_triangle &d = dst[i + u];
 					d.pV0 = base + s.pV0 - vOffset;
 					d.pV1 = base + s.pV1 - vOffset;
@@ -357,27 +408,18 @@ void rt_render_pipe_add_triangles( rt_render_pipe *pRp, rt_vertex *pV, rt_triang
 				}
 			H.words += 4 * i;
 		}
-		for ( ; i < tCount; ++i )
+		for ( ; i < n; ++i )
 		{
-			const rt_triangle &s = pTr[i + tOffset];
+			const rt_triangle &s = src[i];
 			dst[i].pV0 = base + s.pV0 - vOffset;
 			dst[i].pV1 = base + s.pV1 - vOffset;
 			dst[i].pV2 = base + s.pV2 - vOffset;
 			dst[i].mat = tGroup;
-			H.add( (const uint64_t *) &dst[i], 4 );
+			if ( hashed )
+				im->adding.add( (const uint64_t *) &dst[i], 4 );
 		}
-	}
-	else
-	{
-		im->addingValid = false;
-		for ( rt_ulong i = 0; i < tCount; ++i )
-		{
-			const rt_triangle &s = pTr[i + tOffset];
-			dst[i].pV0 = base + s.pV0 - vOffset;
-			dst[i].pV1 = base + s.pV1 - vOffset;
-			dst[i].pV2 = base + s.pV2 - vOffset;
-			dst[i].mat = tGroup;
-		}
+		done += n;
+		stage_added( im );
 	}
 	pRp->trianglesCount += tCount;
 	pRp->vertexCount += vCount;
@@ -523,6 +565,12 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 	// small scenes are built faster by the host (the GPU builder costs about
 	// 0.1 ms per tree level whatever the size); both give the same tree
 	const bool onGpu = im->gpuBuild == 1 || ( im->gpuBuild == 2 && im->tris.size() >= GPU_BUILD_MIN );
+	if ( im->staging && ( reuse || !onGpu ) )
+	{
+		// (a parameter changed between add and draw: what went ahead is not going to be used)
+		staged_copies_done( im );
+		rt_hip_unstage_geometry( im->hip );
+	}
 	if ( !reuse && onGpu )
 	{
 		// same tree, built in HBM: nothing but the raw geometry crosses PCIe
@@ -567,6 +615,9 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 	if ( rt_hip_upload_lights( im->hip, im->lights.data(), im->lights.size() ) ) die_hip( "light upload" );
 	if ( rt_hip_set_camera( im->hip, &im->cam ) ) die_hip( "camera" );
 	if ( rt_hip_render( im->hip, d_out, 0 ) ) die_hip( "render" );
+	// (the build has waited for its input)
+	im->staging = false;
+	im->stagedV = im->stagedT = 0;
 }
 
 // per-frame reset of :1226-1231: geometry, spheres and lights are consumed
@@ -587,11 +638,22 @@ static void consume_scene( rt_render_pipe *pRp )
 rt_argb *rt_render_pipe_draw( rt_render_pipe *pRp )
 {
 	rt_pipe_impl *im = impl_of( pRp );
-	submit_frame( pRp, nullptr );
 	// rows rendered by this pipe land at the top of screenData (all of it
 	// unless a tile split is set)
-	if ( rt_hip_read_frame( im->hip, pRp->screenData ) )
-		die_hip( "frame read-back" );
+	if ( im->screenPinned )
+	{
+		// page-locked memory is mapped into the device's address space: the last kernel of the frame stores the
+		// pixels straight into it across PCIe, which takes half as long as a copy of the finished frame behind it
+		submit_frame( pRp, pRp->screenData );
+		if ( rt_hip_sync( im->hip ) )
+			die_hip( "frame" );
+	}
+	else
+	{
+		submit_frame( pRp, nullptr );
+		if ( rt_hip_read_frame( im->hip, pRp->screenData ) )
+			die_hip( "frame read-back" );
+	}
 	consume_scene( pRp );
 	return pRp->screenData;
 }
@@ -615,6 +677,7 @@ void rt_render_pipe_cleanup( rt_render_pipe *pRp )
 	pRp->screenData = NULL;
 	if ( pRp->impl )
 	{
+		staged_copies_done( pRp->impl );
 		pRp->impl->verts.release();
 		pRp->impl->tris.release();
 		rt_hip_destroy( pRp->impl->hip );

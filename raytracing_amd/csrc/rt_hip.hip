@@ -2124,6 +2124,7 @@ struct rt_hip_ctx
 	int maxGrid = 0;
 	int launchWaves = RT_OCC_CAP;                     // RT_PARAM_LAUNCH_WAVES
 	int pruneLeaves = 0;                              // RT_PARAM_PRUNE_LEAVES (trees built by rt_hip_build_tree)
+	uint64_t stageTicket = 0;                         // geometry copied ahead of the next rt_hip_build_tree (rt_hip_stage_geometry)
 	// HIP events of the last RT_TIMED_FRAMES frames rendered with RT_HIP_TIMING
 	// [frame][(slot * 3 + kernel) * 2 + {start, stop}], then fold start / stop, frame start / stop; of the
 	// start events only that of the first kernel is recorded (enqueue_frame, frame_times)
@@ -2509,6 +2510,8 @@ int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle 
 	o.maxDepth = maxDepth;
 	o.maxPrims = maxPrims;
 	o.pruneLeaves = c->pruneLeaves ? RT_PRUNE_LEAVES_MARGIN : 0.0f;
+	o.stageTicket = c->stageTicket;
+	c->stageTicket = 0;
 	int rc = rt_kdtree_build_device_ex( verts, tris, vertexCount, trianglesCount, &o, c->stream, &t );
 	if ( rc )
 		return fail( "rt_hip_build_tree: builder returned %d (%s)", rc, rt_kdtree_device_last_error() );
@@ -2518,6 +2521,24 @@ int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle 
 		return 1;
 	}
 	return 0;
+}
+
+int rt_hip_stage_geometry( rt_hip_ctx *c, const rt_vertex *verts, uint64_t nVerts, const rt_triangle *tris, uint64_t nTris )
+{
+	if ( !c ) return fail( "null context" );
+	HIPCHK( hipSetDevice( c->device ) );
+	if ( int rc = rt_kdtree_device_stage( &c->stageTicket, verts, nVerts, tris, nTris, c->stream ) )
+	{
+		c->stageTicket = 0;
+		return fail( "rt_hip_stage_geometry: builder returned %d (%s)", rc, rt_kdtree_device_last_error() );
+	}
+	return 0;
+}
+
+void rt_hip_unstage_geometry( rt_hip_ctx *c )
+{
+	if ( c )
+		c->stageTicket = 0;
 }
 
 // A second context on the same GPU that renders the same scene (frames in

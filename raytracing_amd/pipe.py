@@ -56,15 +56,29 @@ class DeviceTree:
     def __init__(self, struct):
         self._s = struct
 
+    @staticmethod
+    def stage(ticket, verts, tris, n_verts, n_tris, stream=None):
+        """rt_kdtree_device_stage: the leading n_verts / n_tris entries go to the device ahead of the build that is
+        given the ticket returned (0 on the first call; 0 comes back when the staging was lost).  The arrays must be
+        the ones the build gets (no copies are made here) and stay as they are until then."""
+        assert verts.dtype == T.vertex and tris.dtype == T.triangle and verts.flags.c_contiguous and tris.flags.c_contiguous
+        L = lib()
+        L.rt_kdtree_device_last_error.restype = C.c_char_p
+        t = C.c_uint64(ticket)
+        rc = L.rt_kdtree_device_stage(C.byref(t), _p(verts), C.c_uint64(n_verts), _p(tris), C.c_uint64(n_tris), C.c_void_p(stream))
+        if rc:
+            raise RtError(f"rt_kdtree_device_stage failed with code {rc}: {L.rt_kdtree_device_last_error().decode()}")
+        return int(t.value)
+
     @classmethod
-    def build(cls, verts, tris, max_depth=10, max_prims=7, stream=None, prune_leaves=0.0):
+    def build(cls, verts, tris, max_depth=10, max_prims=7, stream=None, prune_leaves=0.0, ticket=0):
         from ._lib import BuildOpts
         verts = np.ascontiguousarray(verts, T.vertex)
         tris = np.ascontiguousarray(tris, T.triangle)
         s = DeviceTreeStruct()
         L = lib()
         L.rt_kdtree_device_last_error.restype = C.c_char_p
-        o = BuildOpts(max_depth, max_prims, 0, 0.0, 0, prune_leaves)
+        o = BuildOpts(max_depth, max_prims, 0, 0.0, 0, prune_leaves, ticket)
         rc = L.rt_kdtree_build_device_ex(_p(verts), _p(tris), C.c_uint64(len(verts)), C.c_uint64(len(tris)),
                                          C.byref(o), C.c_void_p(stream), C.byref(s))
         if rc:

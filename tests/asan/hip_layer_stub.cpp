@@ -49,6 +49,12 @@ int rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *v, const rt_triangle *t, 
 	c->sum += touch( v, nv * sizeof( *v ) ) + touch( t, nt * sizeof( *t ) );
 	return 0;
 }
+int rt_hip_stage_geometry( rt_hip_ctx *c, const rt_vertex *v, uint64_t nv, const rt_triangle *t, uint64_t nt )
+{
+	c->sum += touch( v, nv * sizeof( *v ) ) + touch( t, nt * sizeof( *t ) );
+	return 0;
+}
+void rt_hip_unstage_geometry( rt_hip_ctx * ) {}
 int rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n ) { c->sum += touch( m, n * sizeof( *m ) ); return 0; }
 int rt_hip_upload_spheres( rt_hip_ctx *c, const rt_sphere *s, uint64_t n ) { c->sum += touch( s, n * sizeof( *s ) ); return 0; }
 int rt_hip_upload_lights( rt_hip_ctx *c, const rt_point_light *l, uint64_t n ) { c->sum += touch( l, n * sizeof( *l ) ); return 0; }
