@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
 
 #include "rt_kdtree.h"
@@ -1528,7 +1529,7 @@ static int wait_for_staged( Scratch &S, hipStream_t s )
 extern "C" int rt_kdtree_device_stage( uint64_t *ticket, const rt_vertex *verts, uint64_t nVerts, const rt_triangle *tris,
 	uint64_t nTris, void *hipStream )
 {
-	thread_local uint64_t lastTicket = 0;
+	static std::atomic<uint64_t> lastTicket{ 0 };      // (one sequence for all threads: a ticket shown to another thread's builder must not match one of that thread's own)
 	if ( !ticket || ( nVerts && !verts ) || ( nTris && !tris ) || nTris >= ( 1ull << 30 ) )
 		return 1;
 	g_gpu_build_err[0] = 0;
@@ -1538,7 +1539,7 @@ extern "C" int rt_kdtree_device_stage( uint64_t *ticket, const rt_vertex *verts,
 	if ( *ticket == 0 )
 	{
 		S.forget_staged();
-		S.stageTicket = *ticket = ++lastTicket;
+		S.stageTicket = *ticket = lastTicket.fetch_add( 1 ) + 1;
 	}
 	else if ( *ticket != S.stageTicket || nVerts < S.stagedV || nTris < S.stagedT )
 	{
