@@ -365,7 +365,13 @@ DEVI uint2 stack_pop( const StackRef &s, int sp )
 	if ( sp < RT_LDS_STACK )
 		v = g_lds_stack[sp * RT_BLOCK + threadIdx.x];
 	else
-		v = *spill_entry( s, sp );
+	{
+		// (volatile: or the compiler makes ONE load of the two, through a pointer that is either's - a flat load, slower
+		// than an LDS read and waited for together with every record load in flight; entries out here are rare)
+		const volatile uint32_t *q = (const volatile uint32_t *) spill_entry( s, sp );
+		v.x = q[0];
+		v.y = q[1];
+	}
 	return v;
 }
 
