@@ -53,3 +53,27 @@ def test_call_sequences_of_the_render_pipe():
     rp._L.rt_render_pipe_reset_blocks(C.byref(rp._rp))
     assert rp.counts == dict(triangles=0, vertices=0, prims=0, lights=0)
     rp.cleanup()
+
+
+@pytest.mark.parametrize("cache", [0, 1])
+def test_triangles_added_in_pieces_around_the_staging_size(cache):
+    """add_triangles copies, rebases (and, with the tree cache, hashes) a mesh in pieces of 131072 triangles and hands
+    what it has copied to the GPU builder's staging call: counts on both sides of a piece, odd counts, offsets into the
+    caller's arrays, two frames (the second reuses the buffers)."""
+    v, t = random_soup(3, 2)
+    tri = np.zeros(600_000, T.triangle)
+    tri["pV0"], tri["pV1"], tri["pV2"] = 5, 6, 7
+    verts = np.zeros(200_000, T.vertex)
+    rp = RenderPipe(32, 24)
+    rp.set_param(RT_PARAM_GPU_BUILD, 1)
+    rp.set_param(RT_PARAM_TREE_CACHE, cache)
+    for frame in range(2):
+        total = 0
+        for off, cnt in ((0, 131071), (7, 131072), (1, 131073), (3, 1), (0, 0), (11, 262145)):
+            rp.add_triangles(verts, tri, 5, off, 150_000, cnt, 1)
+            total += cnt
+        assert rp.counts["triangles"] == total and rp.counts["vertices"] == 6 * 150_000
+        rp.draw()
+        assert rp.counts == dict(triangles=0, vertices=0, prims=0, lights=0)
+    rp.add_triangles(verts, tri, 5, 0, 150_000, 300_000, 1)
+    rp.cleanup()          # (with geometry handed over and not drawn)
