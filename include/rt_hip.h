@@ -188,7 +188,10 @@ int  rt_hip_set_param( rt_hip_ctx *c, int key, int value );
  * Enqueue one frame on the stream: ray generation, closest-hit / shading
  * passes for every ray slot, colour fold, 8-bit store.  d_out is a DEVICE
  * buffer of w * rt_hip_local_rows() rt_argb, or NULL to use the context's
- * own frame buffer.  Asynchronous.
+ * own frame buffer; page-locked host memory (rt_hip_alloc_host, hipHostMalloc)
+ * does as well - the last kernel then stores the pixels across PCIe, which is
+ * how rt_render_pipe_draw fills screenData (valid after rt_hip_sync).
+ * Asynchronous.
  */
 int  rt_hip_render( rt_hip_ctx *c, void *d_out, unsigned flags );
 /*
