@@ -262,6 +262,22 @@ class HipRenderer:
         check(self._L.rt_hip_adopt_tree(self._c, C.byref(dtree._s)), "rt_hip_adopt_tree")
         dtree._s = None
 
+    def stage_geometry(self, verts, n_verts, tris, n_tris):
+        """rt_hip_stage_geometry: the leading entries of the arrays the next build_tree is given go to the device now
+        (asynchronously; the arrays are used as they are and must stay unchanged until that build)."""
+        assert verts.dtype == T.vertex and tris.dtype == T.triangle and verts.flags.c_contiguous and tris.flags.c_contiguous
+        check(self._L.rt_hip_stage_geometry(self._c, _p(verts), C.c_uint64(n_verts), _p(tris), C.c_uint64(n_tris)), "rt_hip_stage_geometry")
+
+    def unstage_geometry(self):
+        self._L.rt_hip_unstage_geometry(self._c)
+
+    def build_tree(self, verts, tris, max_depth=10, max_prims=7):
+        """rt_hip_build_tree: the tree of this geometry, built on the GPU and installed."""
+        verts = np.ascontiguousarray(verts, T.vertex)
+        tris = np.ascontiguousarray(tris, T.triangle)
+        check(self._L.rt_hip_build_tree(self._c, _p(verts), _p(tris), C.c_uint64(len(verts)), C.c_uint64(len(tris)),
+                                        C.c_int(max_depth), C.c_int(max_prims)), "rt_hip_build_tree")
+
     def share_scene(self, other, scene):
         """Render the scene resident in `other` (same GPU) without a copy of it: tree, materials, spheres, lights
         are read from there; camera, image size and ray budget are set from `scene`."""

@@ -339,6 +339,49 @@ def test_geometry_that_goes_to_the_device_while_it_is_added():
     dev.cleanup()
 
 
+def test_staged_geometry_through_the_hip_layer():
+    """rt_hip_stage_geometry + rt_hip_build_tree called directly (what the render pipe does underneath): a frame from
+    geometry that went ahead in two pieces, a frame after geometry that went ahead was dropped for other arrays
+    (rt_hip_unstage_geometry), and a frame into page-locked host memory - all equal to the frames from uploaded host trees."""
+    import torch
+    sc = scenes.sphere_scene(60, 40, 160, 120, reflect=0.4)
+    v, t = sc.flatten()
+    v2 = v.copy()
+    v2["pos"]["y"] += 2.0
+
+    def reference(verts):
+        r = HipRenderer(0)
+        tree = r.load_scene(sc, FlatTree.build(verts, t, 14, 6))
+        r.render(0)
+        img = r.read_frame().copy()
+        tree.release()
+        r.close()
+        return img
+
+    want, want2 = reference(v), reference(v2)
+    assert not np.array_equal(want, want2)
+    r = HipRenderer(0)
+    r.upload_materials(sc.material_table())
+    r.upload_spheres(sc.sphere_table())
+    r.upload_lights(sc.light_table())
+    r.set_camera(sc.camera)
+    r.set_image(sc.w, sc.h)
+    r.set_param(RT_PARAM_STACK_SIZE, sc.stack_size)
+    r.stage_geometry(v, len(v) // 3, t, 0)
+    r.stage_geometry(v, len(v), t, len(t) // 2)
+    r.build_tree(v, t, 14, 6)
+    r.render(0)
+    assert np.array_equal(r.read_frame(), want)
+    r.stage_geometry(v, len(v), t, len(t))
+    r.unstage_geometry()
+    r.build_tree(v2, t, 14, 6)
+    host = torch.zeros((sc.h, sc.w, 4), dtype=torch.uint8).pin_memory()
+    r.render(0, d_out=host.data_ptr())
+    r.sync()
+    assert np.array_equal(host.numpy(), want2)
+    r.close()
+
+
 def test_render_pipe_kdtree_build_and_params():
     sc, _, _ = IMG["sphere16k_reflect"]
     rp = RenderPipe(sc.w, sc.h)
