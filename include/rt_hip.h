@@ -155,8 +155,10 @@ int  rt_hip_build_tree( rt_hip_ctx *c, const rt_vertex *verts, const rt_triangle
 /* Geometry on its way to the device while the caller is still adding to it (no reference counterpart; see
  * rt_kdtree_device_stage in rt_kdtree.h): what of the leading nVerts / nTris entries earlier calls have not copied
  * is copied now, asynchronously on the context's stream, and the next rt_hip_build_tree of this context - which must
- * be given arrays with the same leading entries, unchanged - copies only the rest.  rt_hip_unstage_geometry: the next
- * rt_hip_build_tree is for other geometry after all. */
+ * be given arrays with the same leading entries, unchanged - copies only the rest.  Returns 0, 1 on failure, and 2
+ * when what had gone ahead was lost (the builder's buffers of this thread went to other geometry in between, another
+ * context's for instance): nothing is staged then, the build copies everything, and a further call would start over
+ * from the first entry.  rt_hip_unstage_geometry: the next rt_hip_build_tree is for other geometry after all. */
 int  rt_hip_stage_geometry( rt_hip_ctx *c, const rt_vertex *verts, uint64_t nVerts, const rt_triangle *tris, uint64_t nTris );
 void rt_hip_unstage_geometry( rt_hip_ctx *c );
 int  rt_hip_upload_materials( rt_hip_ctx *c, const rt_material *m, uint64_t n );

@@ -152,7 +152,7 @@ struct rt_pipe_impl
 	// going to reuse the last one (a 1 M-triangle scene is 44 MB: 0.8 ms on the bus that the draw would wait for):
 	// how many vertices / triangles have been handed to rt_hip_stage_geometry since the last draw
 	size_t stagedV = 0, stagedT = 0;
-	bool staging = false;
+	bool staging = false, stagingLost = false;
 	rt_kdtree_flat lastInfo;          // counts of the tree on the device (arrays released)
 };
 
@@ -171,13 +171,16 @@ static void die_hip( const char *what )
 // Hands what has been added since the last call to the device, once it is a piece worth a copy of its own.
 static void stage_added( rt_pipe_impl *im )
 {
-	if ( im->gpuBuild == 0 || im->treeCache || im->tris.size() < GPU_BUILD_MIN )
+	if ( im->gpuBuild == 0 || im->treeCache || im->stagingLost || im->tris.size() < GPU_BUILD_MIN )
 		return;
 	const size_t fresh = ( im->verts.size() - im->stagedV ) * sizeof( rt_vertex ) + ( im->tris.size() - im->stagedT ) * sizeof( rt_triangle );
 	if ( fresh < STAGE_BYTES )
 		return;
-	if ( rt_hip_stage_geometry( im->hip, im->verts.data(), im->verts.size(), im->tris.data(), im->tris.size() ) )
+	const int rc = rt_hip_stage_geometry( im->hip, im->verts.data(), im->verts.size(), im->tris.data(), im->tris.size() );
+	if ( rc == 1 )
 		die_hip( "geometry upload" );
+	if ( rc == 2 )
+		im->stagingLost = true;          // (another pipe of this thread uses the builder: this frame's build copies everything)
 	im->stagedV = im->verts.size();
 	im->stagedT = im->tris.size();
 	im->staging = true;
@@ -236,6 +239,7 @@ void rt_init_buffers( rt_render_pipe *pRp )
 		rt_hip_unstage_geometry( im->hip );
 		im->staging = false;
 	}
+	im->stagingLost = false;
 	im->stagedV = im->stagedT = 0;
 	im->verts.clear();
 	im->tris.clear();
@@ -616,7 +620,7 @@ static void submit_frame( rt_render_pipe *pRp, void *d_out )
 	if ( rt_hip_set_camera( im->hip, &im->cam ) ) die_hip( "camera" );
 	if ( rt_hip_render( im->hip, d_out, 0 ) ) die_hip( "render" );
 	// (the build has waited for its input)
-	im->staging = false;
+	im->staging = im->stagingLost = false;
 	im->stagedV = im->stagedT = 0;
 }
 

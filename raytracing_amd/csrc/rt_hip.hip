@@ -2533,12 +2533,14 @@ int rt_hip_stage_geometry( rt_hip_ctx *c, const rt_vertex *verts, uint64_t nVert
 {
 	if ( !c ) return fail( "null context" );
 	HIPCHK( hipSetDevice( c->device ) );
+	const bool begun = c->stageTicket != 0;
 	if ( int rc = rt_kdtree_device_stage( &c->stageTicket, verts, nVerts, tris, nTris, c->stream ) )
 	{
 		c->stageTicket = 0;
 		return fail( "rt_hip_stage_geometry: builder returned %d (%s)", rc, rt_kdtree_device_last_error() );
 	}
-	return 0;
+	// (the builder's buffers went to other geometry since the last call: nothing is staged any more)
+	return begun && c->stageTicket == 0 ? 2 : 0;
 }
 
 void rt_hip_unstage_geometry( rt_hip_ctx *c )

@@ -266,7 +266,11 @@ class HipRenderer:
         """rt_hip_stage_geometry: the leading entries of the arrays the next build_tree is given go to the device now
         (asynchronously; the arrays are used as they are and must stay unchanged until that build)."""
         assert verts.dtype == T.vertex and tris.dtype == T.triangle and verts.flags.c_contiguous and tris.flags.c_contiguous
-        check(self._L.rt_hip_stage_geometry(self._c, _p(verts), C.c_uint64(n_verts), _p(tris), C.c_uint64(n_tris)), "rt_hip_stage_geometry")
+        rc = self._L.rt_hip_stage_geometry(self._c, _p(verts), C.c_uint64(n_verts), _p(tris), C.c_uint64(n_tris))
+        if rc == 2:
+            return False          # what had gone ahead was lost to other geometry: the build copies everything
+        check(rc, "rt_hip_stage_geometry")
+        return True
 
     def unstage_geometry(self):
         self._L.rt_hip_unstage_geometry(self._c)

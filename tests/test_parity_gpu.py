@@ -335,8 +335,21 @@ def test_geometry_that_goes_to_the_device_while_it_is_added():
     dev.set_param(RT_PARAM_GPU_BUILD, 1)
     add(dev, v)
     assert np.array_equal(dev.draw(), frames[0])
+    # two pipes of one thread that take turns, call by call: each loses what went ahead to the other (the builder's
+    # input buffers belong to the thread), stops sending ahead for the frame, and its draw copies everything
+    dev2 = pipe(1)
+    for rp in (dev, dev2):
+        for k in sorted(base.materials):
+            rp.add_material(base.materials[k], k)
+        for l in base.lights:
+            rp.add_light(l)
+    for first, count, group in ((0, 0, 0), (0, 50_001, 0), (50_001, 49_999, 1), (100_000, 20_000, 0)):
+        for rp, verts in ((dev, v), (dev2, v2)):
+            rp.add_triangles(verts, t, 0, first, 150_000 if count == 0 else len(verts), count, group)
+    assert np.array_equal(dev2.draw(), frames[1]) and np.array_equal(dev.draw(), frames[0])
     host.cleanup()
     dev.cleanup()
+    dev2.cleanup()
 
 
 def test_staged_geometry_through_the_hip_layer():
